@@ -1,0 +1,192 @@
+/* pengk.h -- C ABI of the MI355X (gfx950) hot path of PEnG-motif.
+ *
+ * The reference (soedinglab/PEnG-motif) has no FFI: its hot path sits behind three C++ classes.
+ * This header is the thin extern "C" layer the host-side mirrors of those classes
+ * (peng-motif_amd/host/) call; every entry point names the reference function it replaces
+ * (file:line relative to the reference tree).  Plain pointers and sizes only; no HIP, torch or
+ * C++ types cross the boundary.  All functions return PENGK_OK (0) or a PENGK_ERR_* code and never
+ * throw; pengk_last_error() describes the last failure of the calling thread.
+ *
+ * Pointer naming: `d_` = device memory (hipMalloc'ed by the caller, e.g. through pengk_malloc or a
+ * torch tensor's data_ptr()), `h_` = host memory.  Work is enqueued on the context's stream;
+ * functions taking only d_ pointers do not synchronise with the host.
+ *
+ * Encodings (identical to the reference):
+ *   pattern id   little-endian base 4, first base = least significant digit (src/base_pattern.h:24-29)
+ *   IUPAC id     little-endian base 11, letters A C G T S W R Y M K N = 0..10 (src/iupac_pattern.h:26-29)
+ *   BaMM id      big-endian (k+1)-mer id (src/shared/Sequence.cpp:21-33)
+ *   V layout     V[0] (4) | V[1] (16) | V[2] (64) floats, 84 in all; bg counts likewise
+ *
+ * Packed sequence layout in HBM:
+ *   words   2 bits per base (A,C,G,T = 0..3), base g in bits [2(g%32), 2(g%32)+2) of 64-bit word g/32;
+ *           only the bases of "visited runs" (scan rule of src/base_pattern.cpp:347-381) are stored,
+ *           back to back; PENGK_FRONT_PAD_BASES zero bases in front, >= 64 behind.
+ *   items   one 64-bit record per scan item: bits 0..39 stream offset of the first window's first
+ *           base, bits 40..55 number of windows (1..65535), bit 56 = item continues the previous
+ *           item's run (its predecessor windows are stored immediately in front).
+ */
+#ifndef PENGK_H_
+#define PENGK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library itself is built with -fvisibility=hidden */
+#endif
+
+#define PENGK_VERSION 100
+
+#define PENGK_OK 0
+#define PENGK_ERR_ARG 1         /* bad argument (NULL, odd/unsupported W, order > 2, ...) */
+#define PENGK_ERR_DEVICE 2      /* no usable gfx950 device / HIP runtime error */
+#define PENGK_ERR_RANGE 3       /* a 32-bit count bin could overflow on this shard */
+#define PENGK_ERR_UNSUPPORTED 4 /* operation not defined for this input (see function) */
+#define PENGK_ERR_NOMEM 5
+
+#define PENGK_MIN_W 4
+#define PENGK_MAX_W 14
+#define PENGK_FRONT_PAD_BASES 64
+#define PENGK_DEFAULT_ITEM_WINDOWS 256
+#define PENGK_MIN_ITEM_WINDOWS 64
+
+typedef struct pengk_ctx pengk_ctx;
+
+/* ---- lifecycle, errors, device memory ------------------------------------------------------- */
+int pengk_version(void);
+const char* pengk_last_error(void);
+const char* pengk_error_name(int code);
+
+/* Binds a context to HIP device `device` and creates its stream.  Fails with PENGK_ERR_DEVICE when
+ * no GPU is present -- there is no CPU fallback in this library. */
+int pengk_create(int device, pengk_ctx** out);
+int pengk_destroy(pengk_ctx* ctx);
+int pengk_synchronize(pengk_ctx* ctx);
+/* hipStream_t of the context (for callers that record their own events). */
+void* pengk_stream(pengk_ctx* ctx);
+/* Re-target the context to an externally owned hipStream_t (e.g. torch's current stream). */
+int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
+
+int pengk_malloc(pengk_ctx* ctx, size_t bytes, void** d_out);
+int pengk_free(pengk_ctx* ctx, void* d_ptr);
+int pengk_memcpy_h2d(pengk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* synchronous */
+int pengk_memcpy_d2h(pengk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous */
+int pengk_memset(pengk_ctx* ctx, void* d_dst, int byte, size_t bytes);              /* async */
+
+/* Stream-ordered event timing without exposing HIP types: records an event on the context's stream;
+ * pengk_timer_elapsed_ms synchronises on `stop`. */
+int pengk_timer_create(pengk_ctx* ctx, void** timer_out);
+int pengk_timer_record(pengk_ctx* ctx, void* timer);
+int pengk_timer_elapsed_ms(pengk_ctx* ctx, void* start, void* stop, float* ms_out);
+int pengk_timer_destroy(pengk_ctx* ctx, void* timer);
+
+/* ---- host packer (pure CPU; replaces the per-sequence byte codes + revcomp copies that
+ *      count_patterns walks, src/base_pattern.cpp:339-342, src/shared/Sequence.cpp:4-35) -------- */
+typedef struct pengk_packed {
+  uint64_t* words;       /* 2-bit stream incl. padding */
+  uint64_t n_words;
+  uint64_t* items;       /* scan items */
+  uint64_t n_items;
+  uint64_t n_bases;      /* stored bases (without padding) */
+  uint64_t n_windows;    /* = ltot: number of visited windows (src/base_pattern.cpp:367) */
+  uint64_t max_bin_bound;/* upper bound on any single count bin: sum over runs of ceil(windows/W) */
+  int64_t bg_counts[84]; /* (k+1)-mer counts, k = 0..2, exactly as BackgroundModel counts them incl. the
+                            invalid-base rule (src/shared/BackgroundModel.cpp:60-84) */
+  uint64_t n_sequences;
+  uint64_t max_len;      /* longest input sequence */
+  int W;
+  int item_windows;
+  int all_whole;         /* 1 iff every input sequence is exactly one stored run (no invalid base, L >= W):
+                            then pengk_bg_count can recount bg_counts on the device */
+} pengk_packed;
+
+/* codes: the reference's byte codes (0 = other, A,C,G,T = 1..4) of all sequences back to back;
+ * offs: n_seq+1 offsets into codes.  item_windows: maximum windows per scan item
+ * (>= PENGK_MIN_ITEM_WINDOWS, <= 65535; 0 = PENGK_DEFAULT_ITEM_WINDOWS). */
+int pengk_pack(const uint8_t* h_codes, const int64_t* h_offs, int64_t n_seq, int W, int item_windows,
+               pengk_packed* out);
+void pengk_packed_free(pengk_packed* p);
+
+/* ---- device-resident sequences ------------------------------------------------------------- */
+/* Attach caller-owned device buffers holding a packed stream and its items (layout above).
+ * `all_whole` as in pengk_packed.  The buffers must outlive every later call that scans them. */
+int pengk_set_sequences(pengk_ctx* ctx, const uint64_t* d_words, uint64_t n_words, const uint64_t* d_items,
+                        uint64_t n_items, int W, int item_windows, uint64_t max_bin_bound, int all_whole);
+
+/* Size query + on-device generation of the synthetic input of SURVEY.md 8d (sequences
+ * [seq0, seq0+n_seq) of length L, splitmix64 counter-based, motif GCTGAGTCAT planted in 10 %),
+ * written straight into caller-owned device buffers in the packed layout, then attached as by
+ * pengk_set_sequences.  Bit-identical to the CPU generator the tests use. */
+int pengk_synth_sizes(uint64_t n_seq, uint32_t L, int W, int item_windows, uint64_t* n_words, uint64_t* n_items);
+int pengk_synth_sequences(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t n_seq, uint32_t L, int W,
+                          int item_windows, uint64_t* d_words, uint64_t* d_items);
+
+/* ---- K1: 4^W k-mer count (BasePattern::count_patterns / count_patterns_single_strand,
+ *      src/base_pattern.cpp:331-441) ---------------------------------------------------------------
+ * d_counts: uint32[4^W], overwritten.  both_strands: counts land on the canonical id min(id, rc)
+ * only (run pengk_mirror_counts for the reference's twin copy, :387-392).  d_ltot: uint64 scalar,
+ * overwritten with the number of visited windows.  The non-overlap rule (:361-366) is applied
+ * exactly, with 64-bit positions.  Counts of different shards add (the rule is per sequence). */
+int pengk_count(pengk_ctx* ctx, int both_strands, uint32_t* d_counts, uint64_t* d_ltot);
+int pengk_mirror_counts(pengk_ctx* ctx, int W, uint32_t* d_counts);
+
+/* K1b: background (k+1)-mer counts k = 0..2 (BackgroundModel ctor loop,
+ * src/shared/BackgroundModel.cpp:60-84) -> uint64[84].  Only for inputs whose sequences are all
+ * whole runs (pengk_packed.all_whole); otherwise PENGK_ERR_UNSUPPORTED and the packer's
+ * bg_counts are the source. */
+int pengk_bg_count(pengk_ctx* ctx, uint64_t* d_bg_counts);
+
+/* BackgroundModel::calculateV (src/shared/BackgroundModel.cpp:490-530), interpolated, on device:
+ * uint64[84] counts -> float[84] conditional probabilities.  alpha: 3 host floats. */
+int pengk_bg_model(pengk_ctx* ctx, const uint64_t* d_bg_counts, int K, const float* h_alpha, float* d_V);
+
+/* ---- K2+K3: pattern-space sweep (calculate_bg_probabilities + aggregate_double_strand_background +
+ *      calculate_expected_counts + calculate_log_pvalues + calculate_zscores,
+ *      src/base_pattern.cpp:231-325) ---------------------------------------------------------------
+ * d_bgprob: float[(max_k+1)][4^W] (order-major), strand-aggregated when both_strands.
+ * expected/z/logp use order k <= max_k <= 2.  d_counts must already be mirrored for both strands.
+ * d_ltot: the uint64 scalar pengk_count wrote (after any cross-GPU reduction). */
+int pengk_pattern_stats(pengk_ctx* ctx, int W, int both_strands, int k, int max_k, const float* d_V,
+                        const uint64_t* d_ltot, const uint32_t* d_counts, float* d_bgprob, float* d_expected,
+                        float* d_logp, float* d_z);
+
+/* ---- K4: IUPAC degenerate-pattern aggregation (IUPACPattern::aggregate_attributes_from_basepatterns
+ *      and count_combined_occurences, src/iupac_pattern.cpp:331-473,806-833) -------------------- */
+typedef struct pengk_iupac_stats {
+  uint64_t sites;   /* sum of counts over the distinct underlying k-mers */
+  float bg_p;       /* float32 sum of background probabilities, in the reference's summation order */
+  float expected;   /* float32 sum of expected counts, same order */
+  float zscore;     /* :446 */
+  float log_pvalue; /* :453-470, Bonferroni term included */
+} pengk_iupac_stats;
+
+/* n patterns (host ids) -> n results (host).  d_bgp: the order-k table used for z-scores. */
+int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_t* h_iupac_ids, int64_t n,
+                          const uint32_t* d_counts, const float* d_bgp, const float* d_expected,
+                          pengk_iupac_stats* h_out);
+
+/* ---- K5: EM over the whole 4^W table (Peng::em_optimize_pwms + calculate_prob_odds,
+ *      src/peng.cpp:48-197; row normalisation src/iupac_pattern.cpp:291-303) ----------------------
+ * h_pwms: n_pwm x W x 4 floats, updated in place with the PWM the reference's loop ends on (before the
+ * extra normalisation of the IUPACPattern(ori, pwm) constructor).  Per-element terms are the
+ * reference's float32 expressions; the 4^W-term sums are accumulated in fp64 in a fixed order.
+ * h_iters / h_change (optional): iterations run and last `change` per PWM. */
+int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturation, float threshold,
+             int max_iterations, const uint32_t* d_counts, const float* d_bg, int* h_iters, float* h_change);
+
+/* Device-resident variant for benchmarking / pipelines: d_pwms n_pwm x W x 4 floats in HBM, updated in
+ * place; d_state: n_pwm x 2 int32 scratch {iterations, active}; no host synchronisation. */
+int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold,
+                    int max_iterations, const uint32_t* d_counts, const float* d_bg, int32_t* d_state,
+                    float* d_change);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* PENGK_H_ */

@@ -1,0 +1,313 @@
+// api.hip -- context, device memory, timers and argument checking of the pengk C ABI.
+// The kernels live in count.hip / stats.hip / iupac.hip / em.hip; the host packer in pack.cpp.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "pengk_internal.h"
+
+namespace pengk {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  return fail(PENGK_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+}
+
+int ensure_scratch(pengk_ctx* ctx, void** slot, size_t* have, size_t need) {
+  if (*have >= need) return PENGK_OK;
+  if (*slot) PENGK_HIP(hipFree(*slot));
+  *slot = nullptr;
+  *have = 0;
+  PENGK_HIP(hipMalloc(slot, need));
+  *have = need;
+  return PENGK_OK;
+}
+
+}  // namespace pengk
+
+using namespace pengk;
+
+extern "C" {
+
+int pengk_version(void) { return PENGK_VERSION; }
+const char* pengk_last_error(void) { return g_err; }
+
+const char* pengk_error_name(int code) {
+  switch (code) {
+    case PENGK_OK: return "PENGK_OK";
+    case PENGK_ERR_ARG: return "PENGK_ERR_ARG";
+    case PENGK_ERR_DEVICE: return "PENGK_ERR_DEVICE";
+    case PENGK_ERR_RANGE: return "PENGK_ERR_RANGE";
+    case PENGK_ERR_UNSUPPORTED: return "PENGK_ERR_UNSUPPORTED";
+    case PENGK_ERR_NOMEM: return "PENGK_ERR_NOMEM";
+    default: return "PENGK_ERR_?";
+  }
+}
+
+int pengk_create(int device, pengk_ctx** out) {
+  if (!out) return fail(PENGK_ERR_ARG, "pengk_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(PENGK_ERR_DEVICE, "pengk_create: no HIP device (%s); this library has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(PENGK_ERR_ARG, "pengk_create: device %d out of range [0,%d)", device, n);
+  PENGK_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PENGK_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(PENGK_ERR_DEVICE, "pengk_create: device %d is %s; this build targets gfx950 only", device, prop.gcnArchName);
+  pengk_ctx* c = new (std::nothrow) pengk_ctx();
+  if (!c) return fail(PENGK_ERR_NOMEM, "pengk_create: out of host memory");
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return hip_fail(e, "hipStreamCreate");
+  }
+  c->own_stream = true;
+  *out = c;
+  return PENGK_OK;
+}
+
+int pengk_destroy(pengk_ctx* ctx) {
+  if (!ctx) return PENGK_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_defer) (void)hipFree(ctx->d_defer);
+  if (ctx->d_em_partials) (void)hipFree(ctx->d_em_partials);
+  if (ctx->d_misc) (void)hipFree(ctx->d_misc);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return PENGK_OK;
+}
+
+int pengk_synchronize(pengk_ctx* ctx) {
+  if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  return PENGK_OK;
+}
+
+void* pengk_stream(pengk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int pengk_set_stream(pengk_ctx* ctx, void* s) {
+  if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->stream) PENGK_HIP(hipStreamDestroy(ctx->stream));
+  ctx->stream = (hipStream_t)s;
+  ctx->own_stream = false;
+  return PENGK_OK;
+}
+
+int pengk_malloc(pengk_ctx* ctx, size_t bytes, void** d_out) {
+  if (!ctx || !d_out) return fail(PENGK_ERR_ARG, "pengk_malloc: NULL argument");
+  PENGK_HIP(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(d_out, bytes ? bytes : 1);
+  if (e != hipSuccess) return fail(PENGK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  return PENGK_OK;
+}
+
+int pengk_free(pengk_ctx* ctx, void* d_ptr) {
+  if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  if (d_ptr) {
+    PENGK_HIP(hipStreamSynchronize(ctx->stream));
+    PENGK_HIP(hipFree(d_ptr));
+  }
+  return PENGK_OK;
+}
+
+int pengk_memcpy_h2d(pengk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  if (!ctx || (bytes && (!d_dst || !h_src))) return fail(PENGK_ERR_ARG, "pengk_memcpy_h2d: NULL argument");
+  PENGK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  return PENGK_OK;
+}
+
+int pengk_memcpy_d2h(pengk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  if (!ctx || (bytes && (!h_dst || !d_src))) return fail(PENGK_ERR_ARG, "pengk_memcpy_d2h: NULL argument");
+  PENGK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  return PENGK_OK;
+}
+
+int pengk_memset(pengk_ctx* ctx, void* d_dst, int byte, size_t bytes) {
+  if (!ctx || (bytes && !d_dst)) return fail(PENGK_ERR_ARG, "pengk_memset: NULL argument");
+  PENGK_HIP(hipMemsetAsync(d_dst, byte, bytes, ctx->stream));
+  return PENGK_OK;
+}
+
+int pengk_timer_create(pengk_ctx* ctx, void** out) {
+  if (!ctx || !out) return fail(PENGK_ERR_ARG, "pengk_timer_create: NULL argument");
+  hipEvent_t ev;
+  PENGK_HIP(hipEventCreate(&ev));
+  *out = (void*)ev;
+  return PENGK_OK;
+}
+int pengk_timer_record(pengk_ctx* ctx, void* t) {
+  if (!ctx || !t) return fail(PENGK_ERR_ARG, "pengk_timer_record: NULL argument");
+  PENGK_HIP(hipEventRecord((hipEvent_t)t, ctx->stream));
+  return PENGK_OK;
+}
+int pengk_timer_elapsed_ms(pengk_ctx* ctx, void* a, void* b, float* ms) {
+  if (!ctx || !a || !b || !ms) return fail(PENGK_ERR_ARG, "pengk_timer_elapsed_ms: NULL argument");
+  PENGK_HIP(hipEventSynchronize((hipEvent_t)b));
+  PENGK_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return PENGK_OK;
+}
+int pengk_timer_destroy(pengk_ctx* ctx, void* t) {
+  (void)ctx;
+  if (t) PENGK_HIP(hipEventDestroy((hipEvent_t)t));
+  return PENGK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int pengk_set_sequences(pengk_ctx* ctx, const uint64_t* d_words, uint64_t n_words, const uint64_t* d_items,
+                        uint64_t n_items, int W, int item_windows, uint64_t max_bin_bound, int all_whole) {
+  if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported (even, %d..%d)", W, PENGK_MIN_W, PENGK_MAX_W);
+  if (item_windows < PENGK_MIN_ITEM_WINDOWS || item_windows > 65535)
+    return fail(PENGK_ERR_ARG, "item_windows %d out of range [%d,65535]", item_windows, PENGK_MIN_ITEM_WINDOWS);
+  if (!d_words || n_words < (PENGK_FRONT_PAD_BASES / 32) + 2) return fail(PENGK_ERR_ARG, "packed stream missing or too short");
+  if (n_items && !d_items) return fail(PENGK_ERR_ARG, "items missing");
+  if (n_items >= (1ull << 32)) return fail(PENGK_ERR_RANGE, "too many scan items for one shard (%llu)", (unsigned long long)n_items);
+  ctx->d_words = d_words;
+  ctx->n_words = n_words;
+  ctx->d_items = d_items;
+  ctx->n_items = n_items;
+  ctx->W = W;
+  ctx->item_windows = item_windows;
+  ctx->max_bin_bound = max_bin_bound;
+  ctx->all_whole = all_whole;
+  return PENGK_OK;
+}
+
+int pengk_synth_sizes(uint64_t n_seq, uint32_t L, int W, int item_windows, uint64_t* n_words, uint64_t* n_items) {
+  if (!valid_w(W) || !n_words || !n_items) return fail(PENGK_ERR_ARG, "pengk_synth_sizes: bad argument");
+  if (item_windows == 0) item_windows = PENGK_DEFAULT_ITEM_WINDOWS;
+  if (L < (uint32_t)W) return fail(PENGK_ERR_ARG, "synthetic sequence length %u shorter than W=%d", L, W);
+  const uint64_t nwin = (uint64_t)L - W + 1;
+  const uint64_t per = (nwin + item_windows - 1) / item_windows;
+  *n_items = n_seq * per;
+  const uint64_t bases = PENGK_FRONT_PAD_BASES + n_seq * (uint64_t)L;
+  *n_words = (bases + 31) / 32 + 4;
+  return PENGK_OK;
+}
+
+int pengk_synth_sequences(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t n_seq, uint32_t L, int W,
+                          int item_windows, uint64_t* d_words, uint64_t* d_items) {
+  if (!ctx || !d_words || !d_items) return fail(PENGK_ERR_ARG, "pengk_synth_sequences: NULL argument");
+  if (item_windows == 0) item_windows = PENGK_DEFAULT_ITEM_WINDOWS;
+  uint64_t nw = 0, ni = 0;
+  int rc = pengk_synth_sizes(n_seq, L, W, item_windows, &nw, &ni);
+  if (rc) return rc;
+  if (item_windows < PENGK_MIN_ITEM_WINDOWS || item_windows > 65535) return fail(PENGK_ERR_ARG, "item_windows out of range");
+  rc = launch_synth(ctx, seed, seq0, n_seq, L, W, item_windows, d_words, d_items);
+  if (rc) return rc;
+  const uint64_t nwin = (uint64_t)L - W + 1;
+  return pengk_set_sequences(ctx, d_words, nw, d_items, ni, W, item_windows, n_seq * ((nwin + W - 1) / W), 1);
+}
+
+int pengk_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) {
+  if (!ctx || !d_counts || !d_ltot) return fail(PENGK_ERR_ARG, "pengk_count: NULL argument");
+  if (!ctx->d_words) return fail(PENGK_ERR_ARG, "pengk_count: no sequences attached");
+  if (ctx->max_bin_bound >= (1ull << 32))
+    return fail(PENGK_ERR_RANGE, "a count bin could reach %llu >= 2^32 on this shard; split the input",
+                (unsigned long long)ctx->max_bin_bound);
+  return launch_count(ctx, both ? 1 : 0, d_counts, d_ltot);
+}
+
+int pengk_mirror_counts(pengk_ctx* ctx, int W, uint32_t* d_counts) {
+  if (!ctx || !d_counts) return fail(PENGK_ERR_ARG, "pengk_mirror_counts: NULL argument");
+  if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
+  return launch_mirror(ctx, W, d_counts);
+}
+
+int pengk_bg_count(pengk_ctx* ctx, uint64_t* d_bg) {
+  if (!ctx || !d_bg) return fail(PENGK_ERR_ARG, "pengk_bg_count: NULL argument");
+  if (!ctx->d_words) return fail(PENGK_ERR_ARG, "pengk_bg_count: no sequences attached");
+  if (!ctx->all_whole)
+    return fail(PENGK_ERR_UNSUPPORTED, "pengk_bg_count: input has invalid bases or sequences shorter than W; use pengk_packed.bg_counts");
+  return launch_bg_count(ctx, d_bg);
+}
+
+int pengk_bg_model(pengk_ctx* ctx, const uint64_t* d_bg, int K, const float* h_alpha, float* d_V) {
+  if (!ctx || !d_bg || !h_alpha || !d_V) return fail(PENGK_ERR_ARG, "pengk_bg_model: NULL argument");
+  if (K < 0 || K > 2) return fail(PENGK_ERR_ARG, "background order %d unsupported (0..2)", K);
+  return launch_bg_model(ctx, d_bg, K, h_alpha, d_V);
+}
+
+int pengk_pattern_stats(pengk_ctx* ctx, int W, int both, int k, int max_k, const float* d_V, const uint64_t* d_ltot,
+                        const uint32_t* d_counts, float* d_bgprob, float* d_expected, float* d_logp, float* d_z) {
+  if (!ctx || !d_V || !d_ltot || !d_counts || !d_bgprob || !d_expected || !d_logp || !d_z)
+    return fail(PENGK_ERR_ARG, "pengk_pattern_stats: NULL argument");
+  if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
+  if (k < 0 || max_k > 2 || k > max_k || max_k > W - 1) return fail(PENGK_ERR_ARG, "background orders k=%d max_k=%d unsupported", k, max_k);
+  return launch_stats(ctx, W, both ? 1 : 0, k, max_k, d_V, d_ltot, d_counts, d_bgprob, d_expected, d_logp, d_z);
+}
+
+int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids, int64_t n, const uint32_t* d_counts,
+                          const float* d_bgp, const float* d_expected, pengk_iupac_stats* h_out) {
+  if (!ctx || (n && (!h_ids || !h_out)) || !d_counts || !d_bgp || !d_expected)
+    return fail(PENGK_ERR_ARG, "pengk_iupac_aggregate: NULL argument");
+  if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
+  if (n < 0) return fail(PENGK_ERR_ARG, "negative pattern count");
+  if (n == 0) return PENGK_OK;
+  return launch_iupac(ctx, W, both ? 1 : 0, h_ids, n, d_counts, d_bgp, d_expected, h_out);
+}
+
+int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
+                    const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
+  if (!ctx || !d_pwms || !d_counts || !d_bg || !d_state || !d_change) return fail(PENGK_ERR_ARG, "pengk_em_device: NULL argument");
+  if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
+  if (n_pwm < 0 || max_it < 0) return fail(PENGK_ERR_ARG, "negative count");
+  if (n_pwm == 0) return PENGK_OK;
+  return launch_em(ctx, W, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
+}
+
+int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturation, float threshold, int max_it,
+             const uint32_t* d_counts, const float* d_bg, int* h_iters, float* h_change) {
+  if (!ctx || (n_pwm && !h_pwms) || !d_counts || !d_bg) return fail(PENGK_ERR_ARG, "pengk_em: NULL argument");
+  if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
+  if (n_pwm < 0 || max_it < 0) return fail(PENGK_ERR_ARG, "negative count");
+  if (n_pwm == 0) return PENGK_OK;
+  const size_t pw = (size_t)n_pwm * W * 4 * sizeof(float);
+  const size_t st = (size_t)n_pwm * 2 * sizeof(int32_t);
+  const size_t ch = (size_t)n_pwm * sizeof(float);
+  const size_t need = ((pw + 255) & ~(size_t)255) + ((st + 255) & ~(size_t)255) + ch;
+  int rc = ensure_scratch(ctx, &ctx->d_misc, &ctx->misc_bytes, need);
+  if (rc) return rc;
+  float* d_pwms = (float*)ctx->d_misc;
+  int32_t* d_state = (int32_t*)((char*)ctx->d_misc + ((pw + 255) & ~(size_t)255));
+  float* d_change = (float*)((char*)d_state + ((st + 255) & ~(size_t)255));
+  PENGK_HIP(hipMemcpyAsync(d_pwms, h_pwms, pw, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_em(ctx, W, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
+  if (rc) return rc;
+  PENGK_HIP(hipMemcpyAsync(h_pwms, d_pwms, pw, hipMemcpyDeviceToHost, ctx->stream));
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_iters || h_change) {
+    int32_t* tmp = new (std::nothrow) int32_t[(size_t)n_pwm * 2];
+    if (!tmp) return fail(PENGK_ERR_NOMEM, "pengk_em: out of host memory");
+    hipError_t e = hipMemcpy(tmp, d_state, st, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && h_change) e = hipMemcpy(h_change, d_change, ch, hipMemcpyDeviceToHost);
+    if (h_iters)
+      for (int64_t i = 0; i < n_pwm; ++i) h_iters[i] = tmp[2 * i];
+    delete[] tmp;
+    if (e != hipSuccess) return hip_fail(e, "pengk_em: copy back");
+  }
+  return PENGK_OK;
+}
+
+}  // extern "C"

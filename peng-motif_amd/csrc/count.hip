@@ -1,0 +1,471 @@
+// count.hip -- K1: the 4^W k-mer count over the 2-bit packed stream (gfx950).
+//
+// Replaces BasePattern::count_patterns / count_patterns_single_strand
+// (src/base_pattern.cpp:331-441), the count mirror (:387-392), the background (k+1)-mer count
+// (src/shared/BackgroundModel.cpp:60-84) and BackgroundModel::calculateV (:490-530).
+//
+// Work decomposition: one lane per scan item (<= item_windows windows of one visited run; the
+// host packer, pack.cpp, has already resolved the N/skip scan rule).  A lane walks its windows
+// left to right with a rolling id / reverse-complement id (2 + 3 ops per base) and keeps the
+// canonical ids of the last W-1 COUNTED windows in a 16-slot register ring; the reference's
+// "last counted occurrence >= W positions back" rule (:361-366) is then exactly
+// "canonical id not in the ring" -- no 4^W last-position table, no second pass.
+//
+// An item that continues a run (long sequences are split) first replays a 3W-3..-base prologue in
+// front of its first window.  If no window of the prologue is suppressed, the ring it leaves is
+// provably the true one (see DESIGN.md "non-overlap rule"); otherwise the item is pushed on a
+// defer list and redone by count_fixup_kernel, which searches backwards for a certified start.
+#include "pengk_internal.h"
+
+namespace pengk {
+
+namespace {
+
+constexpr uint32_t INVALID_ID = 0xFFFFFFFFu;  // ids are < 4^14
+
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t shift) {
+  return __builtin_amdgcn_alignbit(hi, lo, shift);  // ((hi:lo) >> shift)[31:0], shift < 32
+}
+
+template <int W>
+struct Geo {
+  static constexpr int P = ((3 * W - 3 + 15) / 16) * 16;  // prologue bases in front of a continuing item
+  static constexpr uint32_t MASK = (1u << (2 * W)) - 1u;
+  static constexpr int TOP = 2 * (W - 1);
+};
+
+// ---------------------------------------------------------------------------------------------
+// K1 main kernel.  hist: uint32[4^W]; ltot: uint64 scalar; defer[0] = number of deferred items,
+// defer[1..] their indices.
+// ---------------------------------------------------------------------------------------------
+template <int W, bool BOTH>
+__global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__ words32,
+                                                    const uint64_t* __restrict__ items, uint32_t n_items,
+                                                    uint32_t* __restrict__ hist,
+                                                    unsigned long long* __restrict__ ltot,
+                                                    uint32_t* __restrict__ defer) {
+  using G = Geo<W>;
+  const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  unsigned long long my_windows = 0;
+
+  // wave-uniform trip count: every lane of a wave runs the same number of outer iterations
+  for (uint32_t wave_base = lane_global & ~63u; wave_base < n_items; wave_base += stride) {
+    const uint32_t it = wave_base + (threadIdx.x & 63u);
+    const bool live = it < n_items;
+    const uint64_t rec = live ? items[it] : 0ull;
+    uint32_t nw = (uint32_t)((rec >> ITEM_NW_SHIFT) & ITEM_NW_MASK);
+    const uint64_t ws = rec & ITEM_WS_MASK;
+    const bool cont = ((rec >> ITEM_CONT_SHIFT) & 1ull) != 0;
+    my_windows += nw;
+
+    uint32_t ring[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ring[i] = INVALID_ID;
+    uint32_t id = 0, rc = 0;
+
+    // local base 0 of the prologue = global base ws + (W-1) - P (>= 0 thanks to the front pad)
+    const uint64_t g0 = live ? ws + (uint64_t)(W - 1) - (uint64_t)G::P : 0ull;
+    uint64_t wi = g0 >> 4;
+    const uint32_t shift = 2u * (uint32_t)(g0 & 15u);
+    uint32_t lo;
+
+    if (__any(cont ? 1 : 0)) {
+      // full prologue: rebuild the ring of counted windows in front of a continuing item
+      lo = words32[wi];
+      bool dirty = false;
+#pragma unroll
+      for (int ch = 0; ch < G::P / 16; ++ch) {
+        const uint32_t hi = words32[wi + 1];
+        ++wi;
+        const uint32_t chunk = funnel(hi, lo, shift);
+        lo = hi;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int b = ch * 16 + u;
+          const uint32_t c = (chunk >> (2 * u)) & 3u;
+          id = (id >> 2) | (c << G::TOP);
+          rc = ((rc << 2) & G::MASK) | (c ^ 3u);
+          if (b >= W - 1) {
+            const uint32_t can = BOTH ? min(id, rc) : id;
+            bool match = false;
+#pragma unroll
+            for (int d = 1; d <= W - 1; ++d)
+              if (b - d >= W - 1) match |= (can == ring[(u - d) & 15]);
+            dirty |= match;
+            ring[u] = (cont && !match) ? can : INVALID_ID;
+          }
+        }
+      }
+      if (cont && dirty) {  // cannot certify the ring: hand the item to the exact fallback
+        const uint32_t slot = atomicAdd(&defer[0], 1u);
+        defer[1 + slot] = it;
+        nw = 0;
+      }
+    } else {
+      // no lane continues a run: only the last W-1 bases in front of base P matter (id / rc state)
+      wi += (G::P / 16) - 1;
+      lo = words32[wi];
+      const uint32_t hi = words32[wi + 1];
+      ++wi;
+      const uint32_t chunk = funnel(hi, lo, shift);
+      lo = hi;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const uint32_t c = (chunk >> (2 * u)) & 3u;
+        id = (id >> 2) | (c << G::TOP);
+        rc = ((rc << 2) & G::MASK) | (c ^ 3u);
+      }
+    }
+
+    // main scan: window t ends at local base P + t
+    for (uint32_t t0 = 0; t0 < nw; t0 += 16) {
+      const uint32_t hi = words32[wi + 1];
+      ++wi;
+      const uint32_t chunk = funnel(hi, lo, shift);
+      lo = hi;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const uint32_t c = (chunk >> (2 * u)) & 3u;
+        id = (id >> 2) | (c << G::TOP);
+        rc = ((rc << 2) & G::MASK) | (c ^ 3u);
+        const uint32_t can = BOTH ? min(id, rc) : id;
+        bool match = false;
+#pragma unroll
+        for (int d = 1; d <= W - 1; ++d) match |= (can == ring[(u - d) & 15]);
+        ring[u] = match ? INVALID_ID : can;
+        if (!match && t0 + (uint32_t)u < nw)
+          __hip_atomic_fetch_add(&hist[can], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+
+  // ltot: one atomic per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) my_windows += __shfl_down(my_windows, off, 64);
+  if ((threadIdx.x & 63u) == 0 && my_windows) atomicAdd(ltot, my_windows);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact fallback for deferred items (rare: low-complexity runs longer than one item).  One lane per
+// item, plain sequential code: replay from `back` windows in front of the item with an empty ring;
+// the state is certified once 2(W-1) consecutive windows were not suppressed (or the replay started
+// at the head of the run); otherwise quadruple `back`.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t base_at(const uint32_t* __restrict__ words32, uint64_t g) {
+  return (words32[g >> 4] >> (2u * (uint32_t)(g & 15u))) & 3u;
+}
+
+__global__ __launch_bounds__(64) void count_fixup_kernel(const uint32_t* __restrict__ words32,
+                                                         const uint64_t* __restrict__ items, int W, int both,
+                                                         uint32_t* __restrict__ hist,
+                                                         const uint32_t* __restrict__ defer) {
+  const uint32_t n = defer[0];
+  const uint32_t mask = (1u << (2 * W)) - 1u;
+  const int top = 2 * (W - 1);
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const uint32_t it = defer[1 + q];
+    const uint64_t rec = items[it];
+    const uint32_t nw = (uint32_t)((rec >> ITEM_NW_SHIFT) & ITEM_NW_MASK);
+    const uint64_t ws = rec & ITEM_WS_MASK;
+    uint32_t j = it;
+    while ((items[j] >> ITEM_CONT_SHIFT) & 1ull) --j;  // head item of the run (its cont bit is 0)
+    const uint64_t head = items[j] & ITEM_WS_MASK;
+    uint64_t back = 8ull * (uint64_t)(W - 1);
+    for (;;) {
+      const uint64_t p0 = (ws - head > back) ? ws - back : head;
+      bool certified = (p0 == head);
+      uint32_t ring[16];
+      for (int i = 0; i < 16; ++i) ring[i] = INVALID_ID;
+      uint32_t id = 0, rc = 0;
+      for (int b = 0; b < W - 1; ++b) {
+        const uint32_t c = base_at(words32, p0 + b);
+        id = (id >> 2) | (c << top);
+        rc = ((rc << 2) & mask) | (c ^ 3u);
+      }
+      uint32_t clean = 0;
+      bool ok = true;
+      for (uint64_t t = p0; t < ws + nw; ++t) {  // t = stream offset of the window's first base
+        const uint32_t c = base_at(words32, t + (uint64_t)(W - 1));
+        id = (id >> 2) | (c << top);
+        rc = ((rc << 2) & mask) | (c ^ 3u);
+        const uint32_t can = both ? min(id, rc) : id;
+        bool match = false;
+        for (int d = 1; d <= W - 1; ++d) match |= (ring[(uint32_t)(t - d) & 15u] == can);
+        if (t < ws) {
+          clean = match ? 0u : clean + 1u;
+          if (clean >= 2u * (uint32_t)(W - 1)) certified = true;
+        } else {
+          if (!certified) {
+            ok = false;
+            break;
+          }
+          if (!match) __hip_atomic_fetch_add(&hist[can], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ring[(uint32_t)t & 15u] = match ? INVALID_ID : can;
+      }
+      if (ok) break;
+      back *= 4ull;
+    }
+  }
+}
+
+// count[x] = count[revcomp(x)] for x > revcomp(x)  (src/base_pattern.cpp:387-392)
+__global__ __launch_bounds__(256) void mirror_kernel(uint32_t* __restrict__ hist, int W, uint32_t np) {
+  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
+    const uint32_t r = revcomp32(x, W);
+    if (x > r) hist[x] = hist[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1b: (k+1)-mer counts for inputs made of whole sequences.  Each item owns the bases
+// [ws, ws+nw) (+ the W-1 tail bases if it is the last item of its run); per base one 3-mer bin,
+// plus first-base / first-2-mer bins at the head of a run; n1 and n2 follow as marginals:
+//   n2[ab] = sum_c n3[cab] + #runs starting with ab,   n1[a] = sum_b n2[ba] + #runs starting with a.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bg_count_kernel(const uint32_t* __restrict__ words32,
+                                                       const uint64_t* __restrict__ items, uint32_t n_items, int W,
+                                                       unsigned long long* __restrict__ out /* 64 + 16 + 4 raw */) {
+  __shared__ uint32_t h3[64][65];  // [bin][lane-of-wave-slot], padded: private column per (wave-slot, lane%..)
+  __shared__ uint32_t hfirst[20];
+  // 256 threads share 65 columns: column = threadIdx.x & 63 -> 4 waves collide on a column, use atomics
+  for (int i = threadIdx.x; i < 64 * 65; i += blockDim.x) (&h3[0][0])[i] = 0;
+  if (threadIdx.x < 20) hfirst[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t col = threadIdx.x & 63u;
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += gridDim.x * blockDim.x) {
+    const uint64_t rec = items[it];
+    const uint32_t nw = (uint32_t)((rec >> ITEM_NW_SHIFT) & ITEM_NW_MASK);
+    const uint64_t ws = rec & ITEM_WS_MASK;
+    const bool cont = ((rec >> ITEM_CONT_SHIFT) & 1ull) != 0;
+    const bool last = (it + 1 == n_items) || (((items[it + 1] >> ITEM_CONT_SHIFT) & 1ull) == 0);
+    const uint32_t nb = nw + (last ? (uint32_t)(W - 1) : 0u);
+    uint32_t y = 0;
+    uint32_t pos = 2;  // bases of context available in front of the current one (saturates at 2)
+    if (cont) {
+      y = (base_at(words32, ws - 2) << 2) | base_at(words32, ws - 1);
+    } else {
+      pos = 0;
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+      const uint32_t c = base_at(words32, ws + b);
+      y = ((y << 2) | c) & 63u;
+      if (pos >= 2) {
+        atomicAdd(&h3[y][col], 1u);
+      } else if (pos == 1) {
+        atomicAdd(&hfirst[4 + (y & 15u)], 1u);
+        pos = 2;
+      } else {
+        atomicAdd(&hfirst[c], 1u);
+        pos = 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    unsigned long long s = 0;
+    for (int i = 0; i < 64; ++i) s += h3[threadIdx.x][i];
+    if (s) atomicAdd(&out[threadIdx.x], s);
+  } else if (threadIdx.x < 84) {
+    const uint32_t v = hfirst[threadIdx.x - 64];
+    if (v) atomicAdd(&out[threadIdx.x], (unsigned long long)v);
+  }
+}
+
+// raw (n3 | first-2-mer | first-base) -> (n1 | n2 | n3) layout of the C ABI
+__global__ void bg_finish_kernel(const unsigned long long* __restrict__ raw, unsigned long long* __restrict__ out) {
+  const int t = threadIdx.x;
+  __shared__ unsigned long long n2[16];
+  if (t < 16) {
+    unsigned long long s = raw[64 + 4 + t];
+    for (int c = 0; c < 4; ++c) s += raw[c * 16 + t];
+    n2[t] = s;
+    out[4 + t] = s;
+  }
+  __syncthreads();
+  if (t < 4) {
+    unsigned long long s = raw[64 + t];
+    for (int b = 0; b < 4; ++b) s += n2[b * 4 + t];
+    out[t] = s;
+  }
+  if (t < 64) out[20 + t] = raw[t];
+}
+
+// BackgroundModel::calculateV (src/shared/BackgroundModel.cpp:490-530), one thread, float32 in the
+// reference's order.  Counts are converted integer -> float with round-to-nearest (the reference's
+// `int` counters overflow beyond 2^31 bases; below that the results are bit-identical).
+__global__ void bg_model_kernel(const unsigned long long* __restrict__ n, int K, float a0, float a1, float a2,
+                                float* __restrict__ V) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float alpha[3] = {a0, a1, a2};
+  const int off[3] = {0, 4, 20};
+  unsigned long long base_counts = 0;
+  for (int y = 0; y < 4; ++y) base_counts += n[y];
+  for (int y = 0; y < 4; ++y) V[y] = ((float)n[y] + alpha[0] * 0.25f) / ((float)base_counts + alpha[0]);
+  for (int k = 1; k <= K; ++k) {
+    const int ny = 1 << (2 * (k + 1));
+    const int yk = 1 << (2 * k);
+    const unsigned long long* nk = n + off[k];
+    const unsigned long long* nk1 = n + off[k - 1];
+    float* vk = V + off[k];
+    const float* vk1 = V + off[k - 1];
+    for (int y = 0; y < ny; ++y) vk[y] = ((float)nk[y] + alpha[k] * vk1[y % yk]) / ((float)nk1[y / 4] + alpha[k]);
+    for (int g = 0; g < ny; g += 4) {
+      float factor = 0.0f;
+      for (int a = 0; a < 4; ++a) factor += vk[g + a];
+      for (int a = 0; a < 4; ++a) vk[g + a] /= factor;
+    }
+  }
+  for (int i = off[K] + (1 << (2 * (K + 1))); i < 84; ++i) V[i] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic input written directly in the packed layout.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void synth_words_kernel(uint64_t seed, uint64_t seq0, uint64_t n_seq, uint32_t L,
+                                                          uint64_t* __restrict__ words, uint64_t n_words) {
+  const uint64_t motif = 2ull | (1ull << 2) | (3ull << 4) | (2ull << 6) | (0ull << 8) | (2ull << 10) | (3ull << 12) |
+                         (1ull << 14) | (0ull << 16) | (3ull << 18);  // GCTGAGTCAT
+  const uint64_t total = n_seq * (uint64_t)L;
+  for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t v = 0;
+    for (int k = 0; k < 32; ++k) {
+      const uint64_t g = w * 32 + k;
+      if (g < PENGK_FRONT_PAD_BASES) continue;
+      const uint64_t li = g - PENGK_FRONT_PAD_BASES;
+      if (li >= total) break;
+      const uint64_t n = seq0 + li / L;
+      const uint32_t j = (uint32_t)(li % L);
+      uint64_t d = mix64(seed + 0x9E3779B97F4A7C15ull * (n * (uint64_t)L + j + 1)) >> 62;
+      if (L >= 10 && mix64(seed ^ 0xA5A5A5A5ull ^ (n + 1)) % 10 == 0) {
+        const uint64_t q = mix64(seed ^ 0x5A5A5A5Aull ^ (n + 1)) % (L - 9);
+        if (j >= q && j < q + 10) d = (motif >> (2 * (j - q))) & 3ull;
+      }
+      v |= d << (2 * k);
+    }
+    words[w] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void synth_items_kernel(uint64_t n_seq, uint32_t L, int W, uint32_t M,
+                                                          uint64_t* __restrict__ items) {
+  const uint64_t nwin = (uint64_t)L - W + 1;
+  const uint64_t per = (nwin + M - 1) / M;
+  const uint64_t n = n_seq * per;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s = i / per;
+    const uint64_t f = (i % per) * M;
+    const uint64_t nw = nwin - f < M ? nwin - f : M;
+    items[i] = (PENGK_FRONT_PAD_BASES + s * L + f) | (nw << ITEM_NW_SHIFT) | ((uint64_t)(f ? 1 : 0) << ITEM_CONT_SHIFT);
+  }
+}
+
+template <int W>
+int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) {
+  const uint32_t n_items = (uint32_t)ctx->n_items;
+  const uint32_t* w32 = (const uint32_t*)ctx->d_words;
+  if (n_items == 0) return PENGK_OK;
+  const uint32_t blocks_needed = (n_items + 255) / 256;
+  const uint32_t max_blocks = (uint32_t)ctx->num_cu * 8u;
+  const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
+  unsigned long long* lt = (unsigned long long*)d_ltot;
+  if (both)
+    hipLaunchKernelGGL((count_kernel<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, w32, ctx->d_items, n_items,
+                       d_counts, lt, ctx->d_defer);
+  else
+    hipLaunchKernelGGL((count_kernel<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, w32, ctx->d_items, n_items,
+                       d_counts, lt, ctx->d_defer);
+  PENGK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(count_fixup_kernel, dim3(64), dim3(64), 0, ctx->stream, w32, ctx->d_items, W, both, d_counts,
+                     ctx->d_defer);
+  PENGK_HIP(hipGetLastError());
+  return PENGK_OK;
+}
+
+}  // namespace
+
+int launch_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) {
+  const int W = ctx->W;
+  const size_t np = (size_t)1 << (2 * W);
+  // defer list: counter + one slot per item
+  {
+    const size_t need = (ctx->n_items + 2) * sizeof(uint32_t);
+    size_t have = ctx->defer_cap * sizeof(uint32_t);
+    if (have < need) {
+      int rc = ensure_scratch(ctx, (void**)&ctx->d_defer, &have, need);
+      if (rc) return rc;
+      ctx->defer_cap = have / sizeof(uint32_t);
+    }
+  }
+  PENGK_HIP(hipMemsetAsync(ctx->d_defer, 0, sizeof(uint32_t), ctx->stream));
+  PENGK_HIP(hipMemsetAsync(d_counts, 0, np * sizeof(uint32_t), ctx->stream));
+  PENGK_HIP(hipMemsetAsync(d_ltot, 0, sizeof(uint64_t), ctx->stream));
+  switch (W) {
+    case 4: return launch_count_w<4>(ctx, both, d_counts, d_ltot);
+    case 6: return launch_count_w<6>(ctx, both, d_counts, d_ltot);
+    case 8: return launch_count_w<8>(ctx, both, d_counts, d_ltot);
+    case 10: return launch_count_w<10>(ctx, both, d_counts, d_ltot);
+    case 12: return launch_count_w<12>(ctx, both, d_counts, d_ltot);
+    case 14: return launch_count_w<14>(ctx, both, d_counts, d_ltot);
+    default: return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
+  }
+}
+
+int launch_mirror(pengk_ctx* ctx, int W, uint32_t* d_counts) {
+  const uint32_t np = 1u << (2 * W);
+  const uint32_t blocks = (np + 255) / 256 < 4096u ? (np + 255) / 256 : 4096u;
+  hipLaunchKernelGGL(mirror_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_counts, W, np);
+  PENGK_HIP(hipGetLastError());
+  return PENGK_OK;
+}
+
+int launch_bg_count(pengk_ctx* ctx, uint64_t* d_bg) {
+  int rc = ensure_scratch(ctx, &ctx->d_misc, &ctx->misc_bytes, 84 * sizeof(uint64_t));
+  if (rc) return rc;
+  unsigned long long* raw = (unsigned long long*)ctx->d_misc;
+  PENGK_HIP(hipMemsetAsync(raw, 0, 84 * sizeof(uint64_t), ctx->stream));
+  const uint32_t n_items = (uint32_t)ctx->n_items;
+  if (n_items) {
+    const uint32_t need = (n_items + 255) / 256;
+    const uint32_t blocks = need < (uint32_t)ctx->num_cu * 4u ? need : (uint32_t)ctx->num_cu * 4u;
+    hipLaunchKernelGGL(bg_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_words,
+                       ctx->d_items, n_items, ctx->W, raw);
+    PENGK_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(bg_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, raw, (unsigned long long*)d_bg);
+  PENGK_HIP(hipGetLastError());
+  return PENGK_OK;
+}
+
+int launch_bg_model(pengk_ctx* ctx, const uint64_t* d_bg, int K, const float* h_alpha, float* d_V) {
+  hipLaunchKernelGGL(bg_model_kernel, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long*)d_bg, K, h_alpha[0],
+                     h_alpha[1], h_alpha[2], d_V);
+  PENGK_HIP(hipGetLastError());
+  return PENGK_OK;
+}
+
+int launch_synth(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t n_seq, uint32_t L, int W, int item_windows,
+                 uint64_t* d_words, uint64_t* d_items) {
+  uint64_t nw = 0, ni = 0;
+  int rc = pengk_synth_sizes(n_seq, L, W, item_windows, &nw, &ni);
+  if (rc) return rc;
+  hipLaunchKernelGGL(synth_words_kernel, dim3(4096), dim3(256), 0, ctx->stream, seed, seq0, n_seq, L, d_words, nw);
+  PENGK_HIP(hipGetLastError());
+  if (ni) {
+    hipLaunchKernelGGL(synth_items_kernel, dim3(2048), dim3(256), 0, ctx->stream, n_seq, L, W, (uint32_t)item_windows, d_items);
+    PENGK_HIP(hipGetLastError());
+  }
+  return PENGK_OK;
+}
+
+}  // namespace pengk

@@ -1,0 +1,82 @@
+// pengk_internal.h -- shared declarations of the gfx950 hot-path library (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pengk.h"
+
+struct pengk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cu = 256;
+  // attached sequences (caller-owned device memory)
+  const uint64_t* d_words = nullptr;
+  uint64_t n_words = 0;
+  const uint64_t* d_items = nullptr;
+  uint64_t n_items = 0;
+  int W = 0;
+  int item_windows = 0;
+  uint64_t max_bin_bound = 0;
+  int all_whole = 0;
+  // scratch owned by the context
+  uint32_t* d_defer = nullptr;  // deferred item indices + counter in slot 0
+  uint64_t defer_cap = 0;
+  double* d_em_partials = nullptr;
+  size_t em_partials_bytes = 0;
+  void* d_misc = nullptr;  // small staging buffer
+  size_t misc_bytes = 0;
+};
+
+namespace pengk {
+
+int fail(int code, const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+int ensure_scratch(pengk_ctx* ctx, void** slot, size_t* have, size_t need);
+
+#define PENGK_HIP(call)                                   \
+  do {                                                    \
+    hipError_t e_ = (call);                               \
+    if (e_ != hipSuccess) return ::pengk::hip_fail(e_, #call); \
+  } while (0)
+
+inline bool valid_w(int W) { return W >= PENGK_MIN_W && W <= PENGK_MAX_W && (W % 2) == 0; }
+
+// item record fields
+constexpr uint64_t ITEM_WS_MASK = (1ull << 40) - 1;
+constexpr int ITEM_NW_SHIFT = 40;
+constexpr uint64_t ITEM_NW_MASK = 0xFFFF;
+constexpr int ITEM_CONT_SHIFT = 56;
+
+// Reverse complement of a W-digit little-endian base-4 id by bit arithmetic
+// (replaces the half-table lookup of src/base_pattern.cpp:81-97,137-144).
+__host__ __device__ inline uint32_t revcomp32(uint32_t id, int W) {
+  uint32_t v = ~id;
+#if defined(__HIP_DEVICE_COMPILE__)
+  v = __brev(v);
+#else
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+  v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+  v = (v >> 16) | (v << 16);
+#endif
+  v = ((v & 0xAAAAAAAAu) >> 1) | ((v & 0x55555555u) << 1);  // un-reverse the two bits of each digit
+  return v >> (32 - 2 * W);
+}
+
+// launchers implemented in the .hip files
+int launch_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot);
+int launch_mirror(pengk_ctx* ctx, int W, uint32_t* d_counts);
+int launch_bg_count(pengk_ctx* ctx, uint64_t* d_bg);
+int launch_bg_model(pengk_ctx* ctx, const uint64_t* d_bg, int K, const float* h_alpha, float* d_V);
+int launch_synth(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t n_seq, uint32_t L, int W, int item_windows,
+                 uint64_t* d_words, uint64_t* d_items);
+int launch_stats(pengk_ctx* ctx, int W, int both, int k, int max_k, const float* d_V, const uint64_t* d_ltot,
+                 const uint32_t* d_counts, float* d_bgprob, float* d_expected, float* d_logp, float* d_z);
+int launch_iupac(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids, int64_t n, const uint32_t* d_counts,
+                 const float* d_bgp, const float* d_expected, pengk_iupac_stats* h_out);
+int launch_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
+              const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change);
+
+}  // namespace pengk

@@ -1,0 +1,133 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/pengk.h declares,
+refuses to run without a GPU (no fallback), and its host packer reproduces the reference's scan
+rule (checked against the oracle's window walk).  No device compute here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import peng_motif_amd as pk
+from oracle import oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "pengk.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pengk_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = pk.lib()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(pk.EXPORTS) == names
+    assert L.pengk_version() == 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pk.PengkError) as e:
+        pk.Context(0)
+    assert e.value.code == pk.ERR_DEVICE
+
+
+def unpack_windows(p, both):
+    """Replay the packed stream + items on the CPU: canonical id of every window, per run."""
+    W = p.W
+    words = p.words
+    def base(g):
+        return (int(words[g >> 5]) >> (2 * (g & 31))) & 3
+    runs = []
+    cur = None
+    for rec in p.items.tolist():
+        ws = rec & ((1 << 40) - 1)
+        nw = (rec >> 40) & 0xFFFF
+        cont = (rec >> 56) & 1
+        if not cont:
+            cur = []
+            runs.append(cur)
+        for t in range(nw):
+            x = 0
+            for q in range(W):
+                x |= base(ws + t + q) << (2 * q)
+            cur.append(min(x, po.revcomp(x, W)) if both else x)
+    return runs
+
+
+def greedy_count(runs, W, NP):
+    counts = np.zeros(NP, np.uint64)
+    for run in runs:
+        last = {}
+        for e, c in enumerate(run):
+            if c not in last or last[c] + W <= e:
+                counts[c] += 1
+                last[c] = e
+    return counts
+
+
+@pytest.mark.parametrize("W,both", [(4, True), (6, True), (6, False), (8, False)])
+def test_packer_reproduces_scan_rule(golden_dir, W, both):
+    codes, offs = po.read_fasta(os.path.join(golden_dir, "torture.fa"))
+    p = pk.Packed(codes, offs, W, 64)
+    want, ltot = po.count(codes, offs, W, False)  # PLUS counts are un-mirrored, fine for comparison
+    assert p.n_windows == ltot
+    runs = unpack_windows(p, False)
+    assert sum(len(r) for r in runs) == ltot
+    got = greedy_count(runs, W, 4 ** W)
+    assert np.array_equal(got, want)
+    if both:
+        want_b, _ = po.count(codes, offs, W, True)
+        got_b = greedy_count(unpack_windows(p, True), W, 4 ** W)
+        canon = np.array([x <= po.revcomp(x, W) for x in range(4 ** W)])
+        assert np.array_equal(got_b[canon], want_b[canon])
+    assert np.array_equal(p.bg_counts, po.bg_counts(codes, offs, 2))
+    assert p.all_whole == 0
+    assert p.max_bin_bound >= int(want.max())
+
+
+def test_packer_items_and_flags(golden_dir):
+    codes, offs = po.read_fasta(os.path.join(golden_dir, "MafK_100seqs.fasta"))
+    p = pk.Packed(codes, offs, 8, 64)
+    assert p.all_whole == 1 and p.n_sequences == 25 and p.max_len == 205
+    # 198 windows per sequence -> 4 items of <= 64 windows, the last three continue the run
+    assert len(p.items) == 25 * 4
+    cont = (p.items >> np.uint64(56)) & np.uint64(1)
+    assert cont.reshape(25, 4).tolist() == [[0, 1, 1, 1]] * 25
+    nw = (p.items >> np.uint64(40)) & np.uint64(0xFFFF)
+    assert nw.reshape(25, 4).sum(axis=1).tolist() == [198] * 25
+    assert p.n_bases == 25 * 205 and p.n_windows == 4950
+    assert np.array_equal(p.bg_counts, po.bg_counts(codes, offs, 2))
+    # front pad is zero, stream starts at base 64
+    assert p.words[0] == 0 and p.words[1] == 0
+    first = [(int(p.words[2]) >> (2 * i)) & 3 for i in range(8)]
+    assert first == (codes[:8] - 1).tolist()
+
+
+def test_packer_argument_errors():
+    codes = np.array([1, 2, 3, 4] * 5, np.uint8)
+    offs = np.array([0, 20], np.int64)
+    for W in (3, 5, 16, 2):
+        with pytest.raises(pk.PengkError) as e:
+            pk.Packed(codes, offs, W)
+        assert e.value.code == pk.ERR_ARG
+    with pytest.raises(pk.PengkError):
+        pk.Packed(codes, offs, 8, 8)  # item_windows below the minimum
+    p = pk.Packed(codes[:0], np.array([0], np.int64), 8)  # empty input is fine
+    assert p.n_windows == 0 and len(p.items) == 0
+
+
+def test_synth_sizes():
+    import ctypes as C
+    nw, ni = C.c_uint64(), C.c_uint64()
+    assert pk.lib().pengk_synth_sizes(1000, 200, 10, 0, C.byref(nw), C.byref(ni)) == 0
+    assert ni.value == 1000 and nw.value == (64 + 200000 + 31) // 32 + 4
+    assert pk.lib().pengk_synth_sizes(10, 300, 10, 64, C.byref(nw), C.byref(ni)) == 0
+    assert ni.value == 10 * 5
+    assert pk.lib().pengk_synth_sizes(10, 8, 10, 64, C.byref(nw), C.byref(ni)) == pk.ERR_ARG

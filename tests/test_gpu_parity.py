@@ -1,0 +1,267 @@
+"""GPU parity: the HIP path, called through the C ABI (libpengk.so), against the oracle on the same
+inputs and against the committed golden vectors of the compiled reference.
+
+Bars (SURVEY.md 8c / BASELINE.md): integer tables bit-exact; bgprob / expected / z bit-exact
+(float32 bit patterns); log-p equal up to 1 float ulp (device libm log vs glibc); IUPAC sums
+bit-exact; EM PWMs <= 1e-6 absolute vs the fp64-accumulating oracle and <= 1e-4 absolute vs the
+reference's own float32 serial sums, iteration counts equal.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import peng_motif_amd as pk
+from oracle import oracle as po
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["mafk100_w8_both", "mafk100_w8_plus", "mafk100_w6_both", "torture_w6_both", "torture_w6_plus",
+         "torture_w4_both", "torture_w8_plus", "mafk_w10_both", "mafk_w10_plus"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pk.Context(0)
+    yield c
+    c.close()
+
+
+def bits_equal(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def ulp_diff(a, b):
+    """max difference in float32 ulps, treating equal infinities as 0."""
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    d = np.abs(ia - ib)
+    d[same] = 0
+    return int(d.max()) if d.size else 0
+
+
+_cpu = {}
+
+
+def cpu_pipeline(golden_dir, name):
+    if name in _cpu:
+        return _cpu[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    W, both, K = int(g["W"]), bool(g["both"]), int(g["K"])
+    codes, offs = po.read_fasta(os.path.join(golden_dir, str(g["fasta"])))
+    n = po.bg_counts(codes, offs, 2)
+    V = po.bg_V(n, 2)
+    counts, ltot = po.count(codes, offs, W, both)
+    bgp = [po.bgprob(W, k, V, both) for k in range(K + 1)]
+    e, lp, z = po.stats(W, counts, bgp[K], ltot)
+    r = dict(g=g, W=W, both=both, K=K, codes=codes, offs=offs, bgcounts=n, V=V, counts=counts, ltot=ltot, bgp=bgp,
+             expected=e, logp=lp, z=z)
+    _cpu[name] = r
+    return r
+
+
+def gpu_tables(ctx, r, item_windows=0):
+    """pack -> upload -> count -> mirror -> bg model -> stats; returns host copies + device handles."""
+    W, both, K = r["W"], r["both"], r["K"]
+    p = pk.Packed(r["codes"], r["offs"], W, item_windows)
+    ctx.upload(p)
+    counts, ltot = ctx.count(both)
+    if both:
+        ctx.mirror(W, counts)
+    bg = ctx.to_device(p.bg_counts.astype(np.uint64))
+    V = ctx.bg_model(bg, 2)
+    bgprob, expected, logp, z = ctx.pattern_stats(W, both, K, K, V, ltot, counts)
+    return dict(p=p, counts=counts, ltot=ltot, V=V, bgprob=bgprob, expected=expected, logp=logp, z=z)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_count_and_sweep_bit_exact(ctx, golden_dir, name):
+    r = cpu_pipeline(golden_dir, name)
+    d = gpu_tables(ctx, r)
+    assert int(d["ltot"].to_host()[0]) == r["ltot"] == int(r["g"]["ltot"])
+    assert bits_equal(d["counts"].to_host().astype(np.uint64), r["counts"])
+    assert bits_equal(d["V"].to_host(), r["V"])
+    bgp = d["bgprob"].to_host()
+    for k in range(r["K"] + 1):
+        assert bits_equal(bgp[k], r["bgp"][k]), "bgp%d" % k
+    assert bits_equal(d["expected"].to_host(), r["expected"])
+    assert bits_equal(d["z"].to_host(), r["z"])
+    assert ulp_diff(d["logp"].to_host(), r["logp"]) <= 1
+    # the seeds the reference selects follow from bit-identical z: run the host selection on the GPU tables
+    seeds = po.select(r["W"], d["z"].to_host(), d["counts"].to_host().astype(np.uint64), 10.0, 3, not r["both"], True)
+    assert bits_equal(seeds, r["g"]["seeds"])
+
+
+@pytest.mark.parametrize("name", ["torture_w6_both", "torture_w6_plus", "torture_w8_plus", "mafk100_w8_both"])
+def test_count_with_split_items_and_deferred_fixup(ctx, golden_dir, name):
+    """item_windows = 64 splits every run longer than 64 windows: poly-A / (AT)n / tandem repeats force
+    the prologue to fail certification and exercise count_fixup_kernel."""
+    r = cpu_pipeline(golden_dir, name)
+    p = pk.Packed(r["codes"], r["offs"], r["W"], 64)
+    ctx.upload(p)
+    counts, ltot = ctx.count(r["both"])
+    if r["both"]:
+        ctx.mirror(r["W"], counts)
+    assert int(ltot.to_host()[0]) == r["ltot"]
+    assert bits_equal(counts.to_host().astype(np.uint64), r["counts"])
+
+
+def low_complexity_set(seed, n, L):
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for i in range(n):
+        kind = i % 6
+        if kind == 0:
+            s = np.full(L, 1 + (i // 6) % 4, np.uint8)  # homopolymer
+        elif kind == 1:
+            unit = rng.integers(1, 5, size=int(rng.integers(2, 7)))
+            s = np.tile(unit, L // len(unit) + 1)[:L].astype(np.uint8)  # short tandem repeat
+        elif kind == 2:
+            half = rng.integers(1, 5, size=L // 2)
+            s = np.concatenate([half, (5 - half[::-1])])[:L].astype(np.uint8)  # hairpin (revcomp palindrome)
+        elif kind == 3:
+            s = rng.integers(1, 5, size=L).astype(np.uint8)
+            s[rng.integers(0, L, size=3)] = 0  # a few N
+        elif kind == 4:
+            unit = rng.integers(1, 5, size=11)
+            s = np.tile(unit, L // 11 + 1)[:L].astype(np.uint8)  # period > W-1 for W <= 10
+        else:
+            s = rng.integers(1, 5, size=L).astype(np.uint8)
+        seqs.append(s)
+    codes = np.concatenate(seqs)
+    offs = np.arange(n + 1, dtype=np.int64) * L
+    return codes, offs
+
+
+@pytest.mark.parametrize("W,both,L,M", [(6, True, 700, 64), (8, False, 1500, 64), (10, True, 1000, 100), (12, False, 520, 256),
+                                        (4, True, 300, 64), (14, True, 400, 64)])
+def test_count_low_complexity_long_sequences(ctx, W, both, L, M):
+    codes, offs = low_complexity_set(W * 100 + L, 48, L)
+    want, ltot = po.count(codes, offs, W, both)
+    p = pk.Packed(codes, offs, W, M)
+    ctx.upload(p)
+    counts, lt = ctx.count(both)
+    if both:
+        ctx.mirror(W, counts)
+    assert int(lt.to_host()[0]) == ltot
+    got = counts.to_host().astype(np.uint64)
+    assert np.array_equal(got, want), "mismatching bins: %d" % int((got != want).sum())
+
+
+def test_count_empty_and_short_inputs(ctx):
+    # no sequence reaches W bases: no items, zero table
+    codes = np.array([1, 2, 3, 1, 2, 0, 1, 2, 3, 4, 1], np.uint8)
+    offs = np.array([0, 3, 11], np.int64)
+    p = pk.Packed(codes, offs, 6)
+    assert len(p.items) == 0
+    ctx.upload(p)
+    counts, lt = ctx.count(True)
+    assert int(lt.to_host()[0]) == 0 and int(counts.to_host().sum()) == 0
+    with pytest.raises(pk.PengkError) as e:  # bg recount needs whole-sequence runs
+        ctx.bg_count()
+    assert e.value.code == pk.ERR_UNSUPPORTED
+
+
+def test_device_bg_count_matches_packer_and_oracle(ctx, golden_dir):
+    codes, offs = po.read_fasta(os.path.join(golden_dir, "MafK.fasta"))
+    for M in (64, 0):
+        p = pk.Packed(codes, offs, 10, M)
+        assert p.all_whole == 1
+        ctx.upload(p)
+        got = ctx.bg_count().to_host().astype(np.int64)
+        assert np.array_equal(got, p.bg_counts)
+        assert np.array_equal(got, po.bg_counts(codes, offs, 2))
+
+
+def test_synthetic_generator_matches_cpu(ctx):
+    """pengk_synth_sequences == the counter-based generator of SURVEY.md 8d (oracle po_synth)."""
+    n, L, W = 3000, 200, 10
+    codes, offs = po.synth(1, 1234, n, L)
+    p = pk.Packed(codes, offs, W)
+    words, items, nw, ni = ctx.synth(1, 1234, n, L, W)
+    assert nw == len(p.words) and ni == len(p.items)
+    assert np.array_equal(words.to_host(), p.words)
+    assert np.array_equal(items.to_host()[:ni], p.items)
+    counts, lt = ctx.count(False)
+    want, ltot = po.count(codes, offs, W, False)
+    assert int(lt.to_host()[0]) == ltot
+    assert np.array_equal(counts.to_host().astype(np.uint64), want)
+    assert np.array_equal(ctx.bg_count().to_host().astype(np.int64), po.bg_counts(codes, offs, 2))
+
+
+@pytest.mark.parametrize("name", ["mafk100_w8_both", "torture_w8_plus", "torture_w6_both", "mafk_w10_both", "mafk_w10_plus"])
+def test_iupac_aggregation_bit_exact(ctx, golden_dir, name):
+    r = cpu_pipeline(golden_dir, name)
+    g = r["g"]
+    d = gpu_tables(ctx, r)
+    ids = g["iupac_ids"]
+    bgp_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[r["K"]])
+    out = ctx.iupac_aggregate(r["W"], r["both"], ids, d["counts"], bgp_k, d["expected"])
+    assert np.array_equal(out["sites"], g["iupac_sites"])
+    assert np.array_equal(out["sites"], g["iupac_cc"])
+    fb = g["iupac_fbits"]
+    for j, f in enumerate(["bg_p", "expected", "zscore", "log_pvalue"]):
+        assert np.array_equal(out[f].view(np.uint32), fb[:, j]), f
+
+
+@pytest.mark.parametrize("name", ["mafk100_w8_both", "mafk100_w8_plus", "torture_w6_plus", "mafk_w10_both", "mafk_w10_plus"])
+def test_em_against_oracle_and_reference(ctx, golden_dir, name):
+    r = cpu_pipeline(golden_dir, name)
+    g = r["g"]
+    W, K = r["W"], r["K"]
+    if len(g["pwm_ids"]) == 0:
+        pytest.skip("no PWMs in this case")
+    d = gpu_tables(ctx, r)
+    bg_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K])
+    pw, iters, change = ctx.em(W, g["pwm_pre"], d["counts"], bg_k, 1e4, 0.08, 10)
+    dev64 = 0.0
+    devref = 0.0
+    for i in range(len(g["pwm_ids"])):
+        p1, it1, ch1 = po.em(W, r["counts"], r["bgp"][K], g["pwm_pre"][i], 1e4, 0.08, 10, mode=1, final_norm=False)
+        assert iters[i] == it1 == int(g["em_iters"][i])
+        dev64 = max(dev64, float(np.abs(pw[i].astype(np.float64) - p1).max()))
+        # the reference's constructor normalises once more (src/iupac_pattern.cpp:61)
+        fin = pw[i] / pw[i].sum(axis=1, keepdims=True, dtype=np.float32)
+        devref = max(devref, float(np.abs(fin.astype(np.float64) - g["pwm_post"][i]).max()))
+        assert abs(float(change[i]) - ch1) <= 1e-5
+    assert dev64 <= 1e-6, dev64     # vs the fp64-accumulating restatement
+    assert devref <= 1e-4, devref   # vs the reference's float32 serial sums (its own error envelope)
+
+
+def test_em_single_iteration_accumulators(ctx, golden_dir):
+    """One EM step with threshold 0 / max_iter 1: normalised rows equal the oracle's fp64 accumulation."""
+    r = cpu_pipeline(golden_dir, "mafk100_w8_both")
+    g = r["g"]
+    W, K = r["W"], r["K"]
+    d = gpu_tables(ctx, r)
+    bg_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K])
+    pw, iters, _ = ctx.em(W, g["pwm_pre"], d["counts"], bg_k, 1e4, 0.0, 1)
+    for i in range(len(g["pwm_ids"])):
+        acc = po.em_accumulate(W, r["counts"], r["bgp"][K], g["pwm_pre"][i])
+        want = acc.astype(np.float32)
+        want = want / want.sum(axis=1, keepdims=True, dtype=np.float32)
+        assert iters[i] == 1
+        assert ulp_diff(pw[i], want) <= 2
+
+
+def test_em_many_pwms_batch(ctx, golden_dir):
+    """Config-5 shape in miniature: many seed PWMs (0.7 on the seed base, 0.1 elsewhere), threshold 0."""
+    r = cpu_pipeline(golden_dir, "mafk100_w8_plus")
+    W, K = r["W"], r["K"]
+    d = gpu_tables(ctx, r)
+    bg_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K])
+    order = np.lexsort((np.arange(4 ** W), -r["counts"].astype(np.int64)))[:40]
+    pwms = np.full((len(order), W, 4), 0.1, np.float32)
+    for i, x in enumerate(order):
+        for p_ in range(W):
+            pwms[i, p_, (int(x) >> (2 * p_)) & 3] = 0.7
+    pw, iters, _ = ctx.em(W, pwms, d["counts"], bg_k, 1e4, 0.0, 3)
+    assert (iters == 3).all()
+    for i in range(0, len(order), 7):
+        p1, it1, _ = po.em(W, r["counts"], r["bgp"][K], pwms[i], 1e4, 0.0, 3, mode=1, final_norm=False)
+        assert np.abs(pw[i].astype(np.float64) - p1).max() <= 1e-6
