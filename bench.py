@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--pwms", type=int, default=16, help="seed PWMs for the EM phase (whole job)")
     ap.add_argument("--em-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--count-impl", type=int, default=0, help="0 auto, 1 direct atomics, 2 partitioned")
+    ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results invalid)")
     ap.add_argument("--cpu-sample-seqs", type=int, default=1_500_000)
     args = ap.parse_args()
 
@@ -74,6 +76,9 @@ def main():
     ctx_stream = torch.cuda.Stream(device=dev)
     lib = pk.lib()
     pk._check(lib.pengk_set_stream(ctx.h, ctx_stream.cuda_stream))  # kernels + collectives share one stream
+    ctx.set_option("count_impl", args.count_impl)
+    if args.debug_flags:
+        ctx.set_option("debug_flags", args.debug_flags)
 
     with torch.cuda.stream(ctx_stream):
         # ---- resident input: this rank's shard of the global synthetic set -------------------------

@@ -70,6 +70,14 @@ void* pengk_stream(pengk_ctx* ctx);
 /* Re-target the context to an externally owned hipStream_t (e.g. torch's current stream). */
 int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
 
+/* Tunables / introspection.  Options: "count_impl" 0 = auto, 1 = direct global atomics, 2 = partitioned LDS
+ * histograms (W = 8, 10); "n_windows_hint" = total windows of the attached items (sizes the key buffer
+ * tightly; set it after pengk_set_sequences); "key_cap_override" (test hook) entries per bucket region of the
+ * partitioned count, 0 = automatic.  Info: "deferred_items" (of the last pengk_count;
+ * synchronises), "num_cu". */
+int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value);
+int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value_out);
+
 int pengk_malloc(pengk_ctx* ctx, size_t bytes, void** d_out);
 int pengk_free(pengk_ctx* ctx, void* d_ptr);
 int pengk_memcpy_h2d(pengk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* synchronous */

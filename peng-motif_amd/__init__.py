@@ -21,7 +21,7 @@ FRONT_PAD_BASES = 64
 
 EXPORTS = [
     "pengk_version", "pengk_last_error", "pengk_error_name", "pengk_create", "pengk_destroy", "pengk_synchronize",
-    "pengk_stream", "pengk_set_stream", "pengk_malloc", "pengk_free", "pengk_memcpy_h2d", "pengk_memcpy_d2h",
+    "pengk_stream", "pengk_set_stream", "pengk_set_option", "pengk_get_info", "pengk_malloc", "pengk_free", "pengk_memcpy_h2d", "pengk_memcpy_d2h",
     "pengk_memset", "pengk_timer_create", "pengk_timer_record", "pengk_timer_elapsed_ms", "pengk_timer_destroy",
     "pengk_pack", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
     "pengk_count", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
@@ -64,6 +64,8 @@ def lib():
         L.pengk_stream.restype = vp
         L.pengk_stream.argtypes = [vp]
         L.pengk_set_stream.argtypes = [vp, vp]
+        L.pengk_set_option.argtypes = [vp, C.c_char_p, i64]
+        L.pengk_get_info.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
         L.pengk_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.pengk_free.argtypes = [vp, vp]
         L.pengk_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -194,6 +196,14 @@ class Context:
     def synchronize(self):
         _check(lib().pengk_synchronize(self.h))
 
+    def set_option(self, name, value):
+        _check(lib().pengk_set_option(self.h, name.encode(), int(value)))
+
+    def info(self, name):
+        v = C.c_int64()
+        _check(lib().pengk_get_info(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def empty(self, shape, dtype):
         return DeviceArray(self, shape, dtype)
 
@@ -226,6 +236,7 @@ class Context:
         items = self.to_device(packed.items if len(packed.items) else np.zeros(1, np.uint64))
         self.set_sequences(words, items, len(packed.words), len(packed.items), packed.W, packed.item_windows,
                            packed.max_bin_bound, packed.all_whole)
+        self.set_option("n_windows_hint", packed.n_windows)
         return words, items
 
     def synth(self, seed, seq0, n_seq, L, W, item_windows=0, words=None, items=None):

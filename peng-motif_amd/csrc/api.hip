@@ -90,6 +90,8 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_defer) (void)hipFree(ctx->d_defer);
   if (ctx->d_em_partials) (void)hipFree(ctx->d_em_partials);
   if (ctx->d_misc) (void)hipFree(ctx->d_misc);
+  if (ctx->d_keys) (void)hipFree(ctx->d_keys);
+  if (ctx->d_count_aux) (void)hipFree(ctx->d_count_aux);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return PENGK_OK;
@@ -99,6 +101,46 @@ int pengk_synchronize(pengk_ctx* ctx) {
   if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
   PENGK_HIP(hipStreamSynchronize(ctx->stream));
   return PENGK_OK;
+}
+
+int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx || !name) return fail(PENGK_ERR_ARG, "pengk_set_option: NULL argument");
+  if (strcmp(name, "count_impl") == 0) {
+    if (value < 0 || value > 2) return fail(PENGK_ERR_ARG, "count_impl must be 0 (auto), 1 (direct) or 2 (partition)");
+    ctx->count_impl = (int)value;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "debug_flags") == 0) {
+    ctx->debug_flags = (uint64_t)value;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "key_cap_override") == 0) {
+    ctx->key_cap_override = (uint64_t)value;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "n_windows_hint") == 0) {
+    ctx->n_windows_hint = (uint64_t)value;
+    return PENGK_OK;
+  }
+  return fail(PENGK_ERR_ARG, "unknown option '%s'", name);
+}
+
+int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value) {
+  if (!ctx || !name || !value) return fail(PENGK_ERR_ARG, "pengk_get_info: NULL argument");
+  if (strcmp(name, "deferred_items") == 0) {  // scan items the last pengk_count handed to the exact fallback
+    uint32_t n = 0;
+    if (ctx->d_defer) {
+      PENGK_HIP(hipMemcpyAsync(&n, ctx->d_defer, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+      PENGK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *value = n;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "num_cu") == 0) {
+    *value = ctx->num_cu;
+    return PENGK_OK;
+  }
+  return fail(PENGK_ERR_ARG, "unknown info '%s'", name);
 }
 
 void* pengk_stream(pengk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -191,6 +233,7 @@ int pengk_set_sequences(pengk_ctx* ctx, const uint64_t* d_words, uint64_t n_word
   ctx->item_windows = item_windows;
   ctx->max_bin_bound = max_bin_bound;
   ctx->all_whole = all_whole;
+  ctx->n_windows_hint = 0;
   return PENGK_OK;
 }
 
@@ -217,7 +260,10 @@ int pengk_synth_sequences(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t
   rc = launch_synth(ctx, seed, seq0, n_seq, L, W, item_windows, d_words, d_items);
   if (rc) return rc;
   const uint64_t nwin = (uint64_t)L - W + 1;
-  return pengk_set_sequences(ctx, d_words, nw, d_items, ni, W, item_windows, n_seq * ((nwin + W - 1) / W), 1);
+  rc = pengk_set_sequences(ctx, d_words, nw, d_items, ni, W, item_windows, n_seq * ((nwin + W - 1) / W), 1);
+  if (rc) return rc;
+  ctx->n_windows_hint = n_seq * nwin;
+  return PENGK_OK;
 }
 
 int pengk_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) {

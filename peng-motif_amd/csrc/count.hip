@@ -35,15 +35,13 @@ struct Geo {
 };
 
 // ---------------------------------------------------------------------------------------------
-// K1 main kernel.  hist: uint32[4^W]; ltot: uint64 scalar; defer[0] = number of deferred items,
-// defer[1..] their indices.
+// The scan shared by both K1 variants.  `Emit` receives every COUNTED window: emit(can, active).
+// It is called by all lanes of the wave in lock step (active = this lane has a counted window).
 // ---------------------------------------------------------------------------------------------
-template <int W, bool BOTH>
-__global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__ words32,
-                                                    const uint64_t* __restrict__ items, uint32_t n_items,
-                                                    uint32_t* __restrict__ hist,
-                                                    unsigned long long* __restrict__ ltot,
-                                                    uint32_t* __restrict__ defer) {
+template <int W, bool BOTH, class Emit>
+__device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32, const uint64_t* __restrict__ items,
+                                           uint32_t n_items, unsigned long long* __restrict__ ltot,
+                                           uint32_t* __restrict__ defer, Emit& emit, uint32_t dbg = 0) {
   using G = Geo<W>;
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -118,10 +116,18 @@ __global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__
       }
     }
 
-    // main scan: window t ends at local base P + t
-    for (uint32_t t0 = 0; t0 < nw; t0 += 16) {
-      const uint32_t hi = words32[wi + 1];
+    // main scan: window t ends at local base P + t.  The loop is wave-uniform (longest item of the
+    // wave) so that emitters may use wave-wide operations.
+    uint32_t nw_max = nw;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nw_max = max(nw_max, (uint32_t)__shfl_xor((int)nw_max, off, 64));
+    // the stream word of the NEXT iteration is requested one iteration ahead: vmcnt retires in order, so a
+    // load issued after this iteration's key stores (scatter variant) would wait for all of them
+    uint32_t nxt = (0u < nw) ? words32[wi + 1] : 0u;
+    for (uint32_t t0 = 0; t0 < nw_max; t0 += 16) {
+      const uint32_t hi = nxt;
       ++wi;
+      nxt = (t0 + 16u < nw) ? ((dbg & 16u) ? hi * 2654435761u + t0 : words32[wi + 1]) : 0u;  // dbg: no loads in the loop
       const uint32_t chunk = funnel(hi, lo, shift);
       lo = hi;
 #pragma unroll
@@ -134,8 +140,7 @@ __global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__
 #pragma unroll
         for (int d = 1; d <= W - 1; ++d) match |= (can == ring[(u - d) & 15]);
         ring[u] = match ? INVALID_ID : can;
-        if (!match && t0 + (uint32_t)u < nw)
-          __hip_atomic_fetch_add(&hist[can], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        emit(can, !match && t0 + (uint32_t)u < nw);
       }
     }
   }
@@ -144,6 +149,219 @@ __global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) my_windows += __shfl_down(my_windows, off, 64);
   if ((threadIdx.x & 63u) == 0 && my_windows) atomicAdd(ltot, my_windows);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 variant 1 ("direct"): one device-scope atomic per counted window.  Runs at the chip's
+// scattered-atomic rate (~2.5e10/s measured); kept for W = 4, 6, 12, 14 and as the A/B baseline.
+// hist: uint32[4^W]; ltot: uint64 scalar; defer[0] = number of deferred items, defer[1..] indices.
+// ---------------------------------------------------------------------------------------------
+struct DirectEmit {
+  uint32_t* __restrict__ hist;
+  __device__ __forceinline__ void operator()(uint32_t can, bool active) const {
+    if (active) __hip_atomic_fetch_add(&hist[can], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+
+template <int W, bool BOTH>
+__global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__ words32,
+                                                    const uint64_t* __restrict__ items, uint32_t n_items,
+                                                    uint32_t* __restrict__ hist,
+                                                    unsigned long long* __restrict__ ltot,
+                                                    uint32_t* __restrict__ defer) {
+  DirectEmit e{hist};
+  scan_items<W, BOTH>(words32, items, n_items, ltot, defer, e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 variant 2 ("partition"): LDS-privatised histograms for 4^W bins that do not fit in LDS.
+//
+//   pass A  count_scatter_kernel: the same scan, but a counted window's id is split into
+//           bucket = id & (NB-1) and a 15-bit payload = id >> NBITS.  Every wave owns NB small
+//           rings in LDS (128 x u16 each); whenever a ring completes a group of 64 payloads the
+//           wave writes them as ONE 128-byte line into ITS OWN slice of the bucket's region of a
+//           key buffer in HBM.  The slices are static (region[wave][bucket][slice_cap]): no
+//           reservation atomics -- a first version reserved chunks from 32 shared cursors and spent
+//           8 of its 12 ms queueing on those 32 addresses.  2 B of HBM write per counted window.
+//   pass B  count_hist_kernel: a workgroup owns part of one bucket, keeps the bucket's 2^15 bins in
+//           128 KiB of LDS, streams the slices (16 B per lane) and counts with LDS atomics; the
+//           block histogram is added to a bucket-major table with coalesced atomics.
+//   pass C  count_gather_kernel: table[(payload << NBITS) | bucket] += bucket-major table.
+//
+// Skewed inputs cannot break it: a slice that runs full makes further groups of that (wave, bucket)
+// fall back to direct atomics on the final table (graceful degradation to variant 1).
+// ---------------------------------------------------------------------------------------------
+constexpr int RING_CAP = 128;       // u16 entries per (wave, bucket) ring
+constexpr uint32_t KEY_INVALID = 0xFFFFu;
+constexpr int PAYLOAD_BITS = 15;
+
+// Bucket = NBITS bits from the MIDDLE of the id, payload = the remaining 15 bits squeezed together.
+// The low and high digits must not choose the bucket: a canonical id satisfies id <= revcomp(id), which
+// couples its first and last digits (P(first digit = A,C,G,T) = .4,.3,.2,.1), and low-bit buckets were
+// loaded 1.6 : 0.4 -- every tenth key overflowed its slice into the direct-atomic path.  The middle
+// digits are compared last by that inequality and stay uniform.
+template <int W, int NBITS>
+struct KeySplit {
+  static constexpr int S = ((2 * W - NBITS) / 2) & ~1;  // first bucket bit
+  static constexpr uint32_t LOW = (1u << S) - 1u;
+  static constexpr uint32_t NB = 1u << NBITS;
+  __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> S) & (NB - 1u); }
+  __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & LOW) | ((id >> (S + NBITS)) << S); }
+  __host__ __device__ static inline uint32_t join(uint32_t b, uint32_t p) {
+    return (p & LOW) | (b << S) | ((p >> S) << (S + NBITS));
+  }
+};
+
+template <int NBITS>
+struct ScatterShared {
+  static constexpr int NB = 1 << NBITS;
+  uint32_t ring[4][NB][RING_CAP / 2];  // two 16-bit payloads per word
+  uint32_t fill[4][NB];
+};
+
+// The one LDS instance per workgroup.  It is reached through this accessor, never through a pointer
+// stored in a struct: a generic pointer made the compiler emit flat_load for the ring reads, and a flat
+// access waits for vmcnt(0) -- i.e. for every key store still in flight -- on every flush.
+template <int NBITS>
+__device__ __forceinline__ ScatterShared<NBITS>& scatter_lds() {
+  __shared__ ScatterShared<NBITS> sh;
+  return sh;
+}
+
+// Cross-lane state is kept where the compiler cannot mis-model it: the reservation cursor of bucket
+// b lives in the registers of lane b (read with v_readlane), ring counters are LDS atomics, and ring
+// payloads written by other lanes are read through a volatile pointer.  (A first version kept the
+// cursors in plain LDS words written by lane 0: the compiler legally re-used each lane's stale copy.)
+template <int W, int NBITS>
+struct ScatterEmit {
+  using KS = KeySplit<W, NBITS>;
+  static constexpr int NB = 1 << NBITS;
+  static_assert(NB <= 64, "one lane per bucket holds its write cursor");
+  uint16_t* __restrict__ keys;
+  uint32_t slice_cap;  // entries per (bucket, wave) slice, multiple of 64
+  uint32_t n_waves;    // waves of the grid
+  uint32_t* __restrict__ slice_fill;  // [NB][n_waves] entries written (multiple of 64)
+  uint32_t* __restrict__ hist;
+  uint32_t wave, lane, wave_global;
+  uint32_t my_pos;  // lane b: entries already written to this wave's slice of bucket b
+  uint32_t dbg;     // timing experiments only: bit0 skip the key store, bit1 never flush, bit2 scan only
+
+  // wave-major layout region[wave][bucket][slice_cap]: the 32 slices a wave writes to sit in ~1 MiB, so a
+  // CU's 16 waves touch a few dozen pages instead of 512 (bucket-major was TLB-bound: 11.9 ms vs 4 ms)
+  __device__ __forceinline__ size_t slice_base(uint32_t b) const {
+    return ((size_t)wave_global * NB + b) * slice_cap;
+  }
+
+  // write the 64 ring entries starting at ring index g0 (entries >= nvalid become KEY_INVALID) to the slice;
+  // b, g0, nvalid are wave-uniform
+  __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
+    uint32_t pos = __builtin_amdgcn_readlane(my_pos, b);
+    // lanes 0..31 each move two entries (one dword): the group leaves as one 128-byte line of dword stores
+    uint32_t v = __hip_atomic_load(&scatter_lds<NBITS>().ring[wave][b][((g0 >> 1) + (lane & 31u)) & (RING_CAP / 2 - 1)],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const uint32_t e0 = 2u * (lane & 31u);
+    if (e0 >= nvalid) v |= 0xFFFFu;  // KEY_INVALID in the low half
+    if (e0 + 1u >= nvalid) v |= 0xFFFF0000u;
+    if (pos + 64u <= slice_cap) {
+      if (lane < 32u && !(dbg & 1u)) reinterpret_cast<uint32_t*>(keys + slice_base(b) + pos)[lane] = v;
+      pos += 64;
+      if (lane == b) my_pos = pos;
+    } else if (lane < 32u) {  // slice full: count these windows directly (rare; keeps skewed inputs correct)
+      if (e0 < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v & 0xFFFFu)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e0 + 1u < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v >> 16)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  __device__ __forceinline__ void operator()(uint32_t can, bool active) {
+    const uint32_t b = KS::bucket(can);
+    uint32_t slot = 0;
+    if (dbg & 4u) active = false;
+    if (active) {
+      ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
+      slot = atomicAdd(&sh.fill[wave][b], 1u);
+      reinterpret_cast<uint16_t*>(&sh.ring[wave][b][0])[slot & (RING_CAP - 1)] = (uint16_t)KS::payload(can);
+    }
+    unsigned long long trig = __ballot(active && (slot & 63u) == 63u);
+    if (dbg & 2u) trig = 0;
+    while (trig) {  // wave-uniform: a ring just completed a group of 64
+      const int src = __ffsll((long long)trig) - 1;
+      trig &= trig - 1;
+      const uint32_t fb = __builtin_amdgcn_readlane(b, src);
+      const uint32_t fs = __builtin_amdgcn_readlane(slot, src);
+      __builtin_amdgcn_wave_barrier();
+      flush_group(fb, fs - 63u, 64u);
+    }
+  }
+
+  // end of kernel: partial groups, then publish how much of each slice is filled
+  __device__ __forceinline__ void drain() {
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t b = 0; b < (uint32_t)NB; ++b) {
+      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().fill[wave][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const uint32_t r = f & 63u;
+      if (r) flush_group(b, f & ~63u, r);
+    }
+    if (lane < (uint32_t)NB) slice_fill[(size_t)wave_global * NB + lane] = my_pos;
+  }
+};
+
+template <int W, bool BOTH, int NBITS>
+__global__ __launch_bounds__(256) void count_scatter_kernel(const uint32_t* __restrict__ words32,
+                                                            const uint64_t* __restrict__ items, uint32_t n_items,
+                                                            uint16_t* __restrict__ keys, uint32_t slice_cap,
+                                                            uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
+                                                            unsigned long long* __restrict__ ltot,
+                                                            uint32_t* __restrict__ defer, uint32_t dbg) {
+  static_assert(2 * W - NBITS == PAYLOAD_BITS, "payload must be 15 bits");
+  ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
+  for (uint32_t i = threadIdx.x; i < 4u * (1u << NBITS); i += blockDim.x) (&sh.fill[0][0])[i] = 0;
+  __syncthreads();
+  ScatterEmit<W, NBITS> e{keys, slice_cap, gridDim.x * 4u, slice_fill, hist, threadIdx.x >> 6, threadIdx.x & 63u,
+                       blockIdx.x * 4u + (threadIdx.x >> 6), 0u, dbg};
+  scan_items<W, BOTH>(words32, items, n_items, ltot, defer, e, dbg);
+  e.drain();
+}
+
+// One workgroup = 16 waves = part of one bucket: waves walk the (bucket, producer-wave) slices of their share.
+__global__ __launch_bounds__(1024) void count_hist_kernel(const uint16_t* __restrict__ keys, uint32_t slice_cap,
+                                                          uint32_t n_slices, uint32_t nb,
+                                                          const uint32_t* __restrict__ slice_fill, uint32_t bpb,
+                                                          uint32_t* __restrict__ temp) {
+  extern __shared__ uint32_t h[];  // 2^15 bins
+  const uint32_t b = blockIdx.x / bpb, j = blockIdx.x % bpb;
+  for (uint32_t i = threadIdx.x; i < (1u << PAYLOAD_BITS); i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  const uint32_t per = (n_slices + bpb - 1) / bpb;
+  const uint32_t first = j * per, last = min(n_slices, first + per);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  for (uint32_t s = first + wave; s < last; s += 16) {
+    const uint32_t n8 = slice_fill[(size_t)s * nb + b] >> 3;  // groups of 8 keys (16 B); fill is a multiple of 64
+    const uint4* src = reinterpret_cast<const uint4*>(keys + ((size_t)s * nb + b) * slice_cap);
+    for (uint32_t i = lane; i < n8; i += 64) {
+      const uint4 v = src[i];
+      const uint32_t k[8] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16, v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (k[q] < (1u << PAYLOAD_BITS)) atomicAdd(&h[k[q]], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* dst = temp + ((size_t)b << PAYLOAD_BITS);
+  for (uint32_t i = threadIdx.x; i < (1u << PAYLOAD_BITS); i += blockDim.x) {
+    const uint32_t v = h[i];
+    if (v) __hip_atomic_fetch_add(&dst[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// table[join(bucket, payload)] += temp[bucket][payload]
+template <int W, int NBITS>
+__global__ __launch_bounds__(256) void count_gather_kernel(const uint32_t* __restrict__ temp, uint32_t np,
+                                                           uint32_t* __restrict__ hist) {
+  using KS = KeySplit<W, NBITS>;
+  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
+    const uint32_t v = temp[((size_t)KS::bucket(x) << PAYLOAD_BITS) | KS::payload(x)];
+    if (v) hist[x] += v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,10 +589,8 @@ __global__ __launch_bounds__(256) void synth_items_kernel(uint64_t n_seq, uint32
 }
 
 template <int W>
-int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) {
-  const uint32_t n_items = (uint32_t)ctx->n_items;
+int launch_direct_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items) {
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
-  if (n_items == 0) return PENGK_OK;
   const uint32_t blocks_needed = (n_items + 255) / 256;
   const uint32_t max_blocks = (uint32_t)ctx->num_cu * 8u;
   const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
@@ -386,8 +602,85 @@ int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_lto
     hipLaunchKernelGGL((count_kernel<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, w32, ctx->d_items, n_items,
                        d_counts, lt, ctx->d_defer);
   PENGK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(count_fixup_kernel, dim3(64), dim3(64), 0, ctx->stream, w32, ctx->d_items, W, both, d_counts,
-                     ctx->d_defer);
+  return PENGK_OK;
+}
+
+template <int W>
+int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items) {
+  constexpr int NBITS = 2 * W - PAYLOAD_BITS;
+  constexpr uint32_t NB = 1u << NBITS;
+  const uint32_t np = 1u << (2 * W);
+  const uint32_t* w32 = (const uint32_t*)ctx->d_words;
+  // grid of pass A: LDS (33 KiB per block at NB = 32) admits 4 blocks per CU
+  const uint32_t blocks_needed = (n_items + 255) / 256;
+  const uint32_t max_blocks = (uint32_t)ctx->num_cu * 4u;
+  const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
+  const uint32_t n_waves = blocks * 4u;
+  // static slices region[wave][bucket]: expected share + 50 % + slack, in groups of 64 entries
+  uint64_t windows = ctx->n_windows_hint ? ctx->n_windows_hint : ctx->n_items * (uint64_t)ctx->item_windows;
+  const uint64_t share = windows / ((uint64_t)NB * n_waves);
+  uint64_t cap64 = share + share / 2 + 512;  // 1.5x the uniform share: real genomes are not uniform
+  if (ctx->key_cap_override) cap64 = ctx->key_cap_override;  // test hook: force slices to overflow
+  cap64 = (cap64 + 63) / 64 * 64;
+  if (cap64 >= (1ull << 31)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count (slice of %llu keys)", (unsigned long long)cap64);
+  const uint32_t slice_cap = (uint32_t)cap64;
+  int rc = ensure_scratch(ctx, &ctx->d_keys, &ctx->keys_bytes, (size_t)NB * n_waves * slice_cap * sizeof(uint16_t));
+  if (rc) return rc;
+  const size_t fill_words = ((size_t)NB * n_waves + 63) / 64 * 64;
+  const size_t aux_need = fill_words * sizeof(uint32_t) + (size_t)np * sizeof(uint32_t);  // slice fills | bucket-major table
+  rc = ensure_scratch(ctx, &ctx->d_count_aux, &ctx->count_aux_bytes, aux_need);
+  if (rc) return rc;
+  uint32_t* slice_fill = (uint32_t*)ctx->d_count_aux;
+  uint32_t* temp = slice_fill + fill_words;
+  PENGK_HIP(hipMemsetAsync(ctx->d_count_aux, 0, aux_need, ctx->stream));
+  unsigned long long* lt = (unsigned long long*)d_ltot;
+  uint16_t* keys = (uint16_t*)ctx->d_keys;
+  if (both)
+    hipLaunchKernelGGL((count_scatter_kernel<W, true, NBITS>), dim3(blocks), dim3(256), 0, ctx->stream, w32, ctx->d_items,
+                       n_items, keys, slice_cap, slice_fill, d_counts, lt, ctx->d_defer, (uint32_t)ctx->debug_flags);
+  else
+    hipLaunchKernelGGL((count_scatter_kernel<W, false, NBITS>), dim3(blocks), dim3(256), 0, ctx->stream, w32, ctx->d_items,
+                       n_items, keys, slice_cap, slice_fill, d_counts, lt, ctx->d_defer, (uint32_t)ctx->debug_flags);
+  PENGK_HIP(hipGetLastError());
+  // pass B: one 1024-thread workgroup per CU (128 KiB of LDS), bpb workgroups per bucket
+  static bool attr_set = false;
+  if (!attr_set) {
+    PENGK_HIP(hipFuncSetAttribute((const void*)count_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << PAYLOAD_BITS));
+    attr_set = true;
+  }
+  uint32_t bpb = ((uint32_t)ctx->num_cu * 2u + NB - 1) / NB;
+  const uint64_t per_bucket = windows / NB + 1;
+  const uint32_t useful = (uint32_t)((per_bucket + 65535) / 65536);  // >= 64 Ki keys per workgroup or it is not worth a block
+  if (bpb > useful) bpb = useful;
+  if (bpb > n_waves) bpb = n_waves;
+  if (bpb < 1) bpb = 1;
+  hipLaunchKernelGGL(count_hist_kernel, dim3(NB * bpb), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys, slice_cap, n_waves,
+                     NB, slice_fill, bpb, temp);
+  PENGK_HIP(hipGetLastError());
+  const uint32_t gb = (np + 255) / 256 < 2048u ? (np + 255) / 256 : 2048u;
+  hipLaunchKernelGGL((count_gather_kernel<W, NBITS>), dim3(gb), dim3(256), 0, ctx->stream, temp, np, d_counts);
+  PENGK_HIP(hipGetLastError());
+  return PENGK_OK;
+}
+
+template <int W>
+int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) {
+  const uint32_t n_items = (uint32_t)ctx->n_items;
+  if (n_items == 0) return PENGK_OK;
+  int impl = ctx->count_impl;
+  constexpr bool can_partition = (W == 8 || W == 10);
+  if (impl == 0) impl = can_partition ? 2 : 1;
+  if (impl == 2 && !can_partition) return fail(PENGK_ERR_UNSUPPORTED, "partitioned count is built for W = 8 and 10 only");
+  int rc;
+  if constexpr (can_partition) {
+    rc = impl == 2 ? launch_partition_w<W>(ctx, both, d_counts, d_ltot, n_items)
+                   : launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items);
+  } else {
+    rc = launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(count_fixup_kernel, dim3(64), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->d_words, ctx->d_items, W,
+                     both, d_counts, ctx->d_defer);
   PENGK_HIP(hipGetLastError());
   return PENGK_OK;
 }

@@ -105,10 +105,55 @@ def test_count_with_split_items_and_deferred_fixup(ctx, golden_dir, name):
     p = pk.Packed(r["codes"], r["offs"], r["W"], 64)
     ctx.upload(p)
     counts, ltot = ctx.count(r["both"])
+    deferred = ctx.info("deferred_items")
+    if name.startswith("torture"):
+        assert deferred > 0  # the fallback really ran
     if r["both"]:
         ctx.mirror(r["W"], counts)
     assert int(ltot.to_host()[0]) == r["ltot"]
     assert bits_equal(counts.to_host().astype(np.uint64), r["counts"])
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("name", ["mafk100_w8_both", "torture_w8_plus", "mafk_w10_both", "mafk_w10_plus"])
+def test_count_both_implementations(ctx, golden_dir, name, impl):
+    """direct global atomics (1) and partitioned LDS histograms (2) give the same table."""
+    r = cpu_pipeline(golden_dir, name)
+    p = pk.Packed(r["codes"], r["offs"], r["W"], 64 if "torture" in name else 0)
+    ctx.upload(p)
+    ctx.set_option("count_impl", impl)
+    try:
+        counts, ltot = ctx.count(r["both"])
+        if r["both"]:
+            ctx.mirror(r["W"], counts)
+        assert int(ltot.to_host()[0]) == r["ltot"]
+        assert bits_equal(counts.to_host().astype(np.uint64), r["counts"])
+    finally:
+        ctx.set_option("count_impl", 0)
+
+
+def test_partitioned_count_survives_a_full_bucket_region(ctx):
+    """Skew: every counted window lands in few buckets and the key-buffer hint is far too small, so bucket
+    regions run full and the overflow path (direct atomics) must keep the table exact."""
+    W = 10
+    rng = np.random.default_rng(3)
+    unit = rng.integers(1, 5, size=13).astype(np.uint8)  # period 13 > W: every window is counted, 13 distinct ids
+    L = 500
+    codes = np.tile(np.tile(unit, L // 13 + 1)[:L], 4000)
+    offs = np.arange(4001, dtype=np.int64) * L
+    want, ltot = po.count(codes, offs, W, True)
+    p = pk.Packed(codes, offs, W)
+    ctx.upload(p)
+    ctx.set_option("count_impl", 2)
+    ctx.set_option("key_cap_override", 128)  # two groups per (wave, bucket) slice, then the slices are full
+    try:
+        counts, lt = ctx.count(True)
+        ctx.mirror(W, counts)
+        assert int(lt.to_host()[0]) == ltot
+        assert np.array_equal(counts.to_host().astype(np.uint64), want)
+    finally:
+        ctx.set_option("count_impl", 0)
+        ctx.set_option("key_cap_override", 0)
 
 
 def low_complexity_set(seed, n, L):
