@@ -6,7 +6,7 @@ Workload (BASELINE.json configs[2], the HBM-roofline run): synthetic 10M x 200 b
 timed region), W=10, both strands, background order 2.  One "step" = one full pass of the hot path
 over that batch:
 
-    K1  4^W k-mer count (+ K1b background 3-mer count)      pengk_count / pengk_bg_count
+    K1  4^W k-mer count with K1b (background 3-mers) fused  pengk_count_bg
     C1  all-reduce(sum) of {counts, ltot, bg counts}        torch.distributed (RCCL), N > 1 only
         mirror, background model V                          pengk_mirror_counts / pengk_bg_model
     K2+K3 sweep over 4^W patterns (bgprob, expected, log-p, z)   pengk_pattern_stats
@@ -52,6 +52,7 @@ def main():
 
     import torch
     import peng_motif_amd as pk
+    from peng_motif_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -88,6 +89,8 @@ def main():
         words = torch.empty(nw.value, dtype=torch.int64, device=dev)
         items = torch.empty(max(ni.value, 1), dtype=torch.int64, device=dev)
         ctx.synth(1, rank * nseq, nseq, L, W, 0, words, items)
+        nwin = L - W + 1
+        sharding.check_global_bin_bound(nseq * ((nwin + W - 1) // W), dist)
         counts = torch.empty(NP, dtype=torch.int32, device=dev)           # uint32 bins (bit pattern)
         scal = torch.zeros(85, dtype=torch.int64, device=dev)             # [0:84] bg counts, [84] ltot
         V = torch.empty(84, dtype=torch.float32, device=dev)
@@ -119,13 +122,11 @@ def main():
         def step(timed):
             if timed:
                 ctx.record(ev["count"][0])
-            pk._check(lib.pengk_count(ctx.h, int(both), counts.data_ptr(), scal[84:].data_ptr()))
+            # K1 with K1b fused into the same scan
+            pk._check(lib.pengk_count_bg(ctx.h, int(both), counts.data_ptr(), scal[84:].data_ptr(), scal.data_ptr()))
             if timed:
                 ctx.record(ev["count"][1])
-            pk._check(lib.pengk_bg_count(ctx.h, scal.data_ptr()))
-            if world > 1:
-                dist.all_reduce(counts)   # int32 adds == uint32 adds while the global bin bound < 2^32
-                dist.all_reduce(scal)
+            sharding.allreduce_tables(counts, scal, dist)  # the ONE exchange step (C1); no-op at N = 1
             if both:
                 pk._check(lib.pengk_mirror_counts(ctx.h, W, counts.data_ptr()))
             pk._check(lib.pengk_bg_model(ctx.h, scal.data_ptr(), K, alpha.ctypes.data, V.data_ptr()))

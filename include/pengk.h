@@ -140,6 +140,10 @@ int pengk_synth_sequences(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t
  * exactly, with 64-bit positions.  Counts of different shards add (the rule is per sequence). */
 int pengk_count(pengk_ctx* ctx, int both_strands, uint32_t* d_counts, uint64_t* d_ltot);
 int pengk_mirror_counts(pengk_ctx* ctx, int W, uint32_t* d_counts);
+/* pengk_count with K1b fused into the same scan (the rolling id's top three digits are the 3-mer ending at
+ * the current base): additionally writes uint64[84] background counts as pengk_bg_count would.  Same
+ * restriction as pengk_bg_count (whole-sequence runs), else PENGK_ERR_UNSUPPORTED. */
+int pengk_count_bg(pengk_ctx* ctx, int both_strands, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg_counts);
 
 /* K1b: background (k+1)-mer counts k = 0..2 (BackgroundModel ctor loop,
  * src/shared/BackgroundModel.cpp:60-84) -> uint64[84].  Only for inputs whose sequences are all

@@ -24,7 +24,7 @@ EXPORTS = [
     "pengk_stream", "pengk_set_stream", "pengk_set_option", "pengk_get_info", "pengk_malloc", "pengk_free", "pengk_memcpy_h2d", "pengk_memcpy_d2h",
     "pengk_memset", "pengk_timer_create", "pengk_timer_record", "pengk_timer_elapsed_ms", "pengk_timer_destroy",
     "pengk_pack", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
-    "pengk_count", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
+    "pengk_count", "pengk_count_bg", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
     "pengk_iupac_aggregate", "pengk_em", "pengk_em_device",
 ]
 
@@ -82,6 +82,7 @@ def lib():
         L.pengk_synth_sizes.argtypes = [u64, C.c_uint32, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64)]
         L.pengk_synth_sequences.argtypes = [vp, u64, u64, u64, C.c_uint32, C.c_int, C.c_int, vp, vp]
         L.pengk_count.argtypes = [vp, C.c_int, vp, vp]
+        L.pengk_count_bg.argtypes = [vp, C.c_int, vp, vp, vp]
         L.pengk_mirror_counts.argtypes = [vp, C.c_int, vp]
         L.pengk_bg_count.argtypes = [vp, vp]
         L.pengk_bg_model.argtypes = [vp, vp, C.c_int, vp, vp]
@@ -259,6 +260,13 @@ class Context:
             ltot = self.empty(1, np.uint64)
         _check(lib().pengk_count(self.h, int(both), _ptr(counts), _ptr(ltot)))
         return counts, ltot
+
+    def count_bg(self, both, counts=None, ltot=None, bg=None):
+        counts = counts if counts is not None else self.empty(4 ** self.W, np.uint32)
+        ltot = ltot if ltot is not None else self.empty(1, np.uint64)
+        bg = bg if bg is not None else self.empty(84, np.uint64)
+        _check(lib().pengk_count_bg(self.h, int(both), _ptr(counts), _ptr(ltot), _ptr(bg)))
+        return counts, ltot, bg
 
     def mirror(self, W, counts):
         _check(lib().pengk_mirror_counts(self.h, W, _ptr(counts)))

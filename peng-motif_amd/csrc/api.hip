@@ -91,6 +91,7 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_em_partials) (void)hipFree(ctx->d_em_partials);
   if (ctx->d_misc) (void)hipFree(ctx->d_misc);
   if (ctx->d_keys) (void)hipFree(ctx->d_keys);
+  if (ctx->d_bg_partials) (void)hipFree(ctx->d_bg_partials);
   if (ctx->d_count_aux) (void)hipFree(ctx->d_count_aux);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -272,7 +273,18 @@ int pengk_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) 
   if (ctx->max_bin_bound >= (1ull << 32))
     return fail(PENGK_ERR_RANGE, "a count bin could reach %llu >= 2^32 on this shard; split the input",
                 (unsigned long long)ctx->max_bin_bound);
-  return launch_count(ctx, both ? 1 : 0, d_counts, d_ltot);
+  return launch_count(ctx, both ? 1 : 0, d_counts, d_ltot, nullptr);
+}
+
+int pengk_count_bg(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg) {
+  if (!ctx || !d_counts || !d_ltot || !d_bg) return fail(PENGK_ERR_ARG, "pengk_count_bg: NULL argument");
+  if (!ctx->d_words) return fail(PENGK_ERR_ARG, "pengk_count_bg: no sequences attached");
+  if (!ctx->all_whole)
+    return fail(PENGK_ERR_UNSUPPORTED, "pengk_count_bg: input has invalid bases or sequences shorter than W; use pengk_packed.bg_counts");
+  if (ctx->max_bin_bound >= (1ull << 32))
+    return fail(PENGK_ERR_RANGE, "a count bin could reach %llu >= 2^32 on this shard; split the input",
+                (unsigned long long)ctx->max_bin_bound);
+  return launch_count(ctx, both ? 1 : 0, d_counts, d_ltot, d_bg);
 }
 
 int pengk_mirror_counts(pengk_ctx* ctx, int W, uint32_t* d_counts) {

@@ -38,11 +38,58 @@ struct Geo {
 // The scan shared by both K1 variants.  `Emit` receives every COUNTED window: emit(can, active).
 // It is called by all lanes of the wave in lock step (active = this lane has a counted window).
 // ---------------------------------------------------------------------------------------------
-template <int W, bool BOTH, class Emit>
+// Fused K1b: while the scan rolls the id, the top three digits ARE the 3-mer ending at the current base.
+// Every item owns the bases its windows end on; the first item of a run also owns the run's first W-1
+// bases (counted in the prologue).  Bins live in LDS per wave: [0..63] 3-mers (little-endian digits),
+// [64..67] first base of a run, [68..83] first 2-mer (x0 | x1 << 2).  Only meaningful for inputs made
+// of whole sequences (pengk_packed.all_whole), where runs == sequences.
+struct BgLds {
+  uint32_t bins[4][96];
+};
+__device__ __forceinline__ BgLds& bg_lds() {
+  __shared__ BgLds sh;
+  return sh;
+}
+template <int W, bool BG>
+struct BgCount {
+  uint32_t wave;
+  __device__ __forceinline__ void kmer3(uint32_t id, bool on) const {
+    if (BG && on) atomicAdd(&bg_lds().bins[wave][id >> (2 * W - 6)], 1u);
+  }
+  // base at run position sp (static) of a non-continuing item, id already rolled
+  __device__ __forceinline__ void head(uint32_t id, int sp, bool on) const {
+    if (!BG || !on || sp < 0) return;
+    if (sp == 0) atomicAdd(&bg_lds().bins[wave][64 + (id >> (2 * W - 2))], 1u);
+    else if (sp == 1) atomicAdd(&bg_lds().bins[wave][68 + (id >> (2 * W - 4))], 1u);
+    else atomicAdd(&bg_lds().bins[wave][id >> (2 * W - 6)], 1u);
+  }
+};
+
+template <bool BG>
+__device__ __forceinline__ void bg_begin() {
+  if (BG) {
+    for (uint32_t i = threadIdx.x; i < 4u * 96u; i += blockDim.x) (&bg_lds().bins[0][0])[i] = 0;
+  }
+}
+// block partials [gridDim.x][84]; summed in block order by bg_finish_fused_kernel (deterministic, no atomics)
+template <bool BG>
+__device__ __forceinline__ void bg_end(uint32_t* __restrict__ bg_partials) {
+  if (BG) {
+    __syncthreads();
+    if (threadIdx.x < 84) {
+      const BgLds& b = bg_lds();
+      bg_partials[(size_t)blockIdx.x * 84 + threadIdx.x] =
+          b.bins[0][threadIdx.x] + b.bins[1][threadIdx.x] + b.bins[2][threadIdx.x] + b.bins[3][threadIdx.x];
+    }
+  }
+}
+
+template <int W, bool BOTH, bool BG, class Emit>
 __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32, const uint64_t* __restrict__ items,
                                            uint32_t n_items, unsigned long long* __restrict__ ltot,
                                            uint32_t* __restrict__ defer, Emit& emit, uint32_t dbg = 0) {
   using G = Geo<W>;
+  const BgCount<W, BG> bgc{threadIdx.x >> 6};
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t stride = gridDim.x * blockDim.x;
   unsigned long long my_windows = 0;
@@ -55,6 +102,7 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
     uint32_t nw = (uint32_t)((rec >> ITEM_NW_SHIFT) & ITEM_NW_MASK);
     const uint64_t ws = rec & ITEM_WS_MASK;
     const bool cont = ((rec >> ITEM_CONT_SHIFT) & 1ull) != 0;
+    const uint32_t nw_all = nw;  // a deferred item (nw = 0 below) still owns its bases for the fused K1b
     my_windows += nw;
 
     uint32_t ring[16];
@@ -84,6 +132,7 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
           const uint32_t c = (chunk >> (2 * u)) & 3u;
           id = (id >> 2) | (c << G::TOP);
           rc = ((rc << 2) & G::MASK) | (c ^ 3u);
+          bgc.head(id, b - (G::P - (W - 1)), live && !cont && nw > 0);
           if (b >= W - 1) {
             const uint32_t can = BOTH ? min(id, rc) : id;
             bool match = false;
@@ -113,21 +162,23 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
         const uint32_t c = (chunk >> (2 * u)) & 3u;
         id = (id >> 2) | (c << G::TOP);
         rc = ((rc << 2) & G::MASK) | (c ^ 3u);
+        bgc.head(id, u - (17 - W), live && nw > 0);
       }
     }
 
     // main scan: window t ends at local base P + t.  The loop is wave-uniform (longest item of the
     // wave) so that emitters may use wave-wide operations.
-    uint32_t nw_max = nw;
+    const uint32_t nw_scan = BG ? nw_all : nw;
+    uint32_t nw_max = nw_scan;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nw_max = max(nw_max, (uint32_t)__shfl_xor((int)nw_max, off, 64));
     // the stream word of the NEXT iteration is requested one iteration ahead: vmcnt retires in order, so a
     // load issued after this iteration's key stores (scatter variant) would wait for all of them
-    uint32_t nxt = (0u < nw) ? words32[wi + 1] : 0u;
+    uint32_t nxt = (0u < nw_scan) ? words32[wi + 1] : 0u;
     for (uint32_t t0 = 0; t0 < nw_max; t0 += 16) {
       const uint32_t hi = nxt;
       ++wi;
-      nxt = (t0 + 16u < nw) ? ((dbg & 16u) ? hi * 2654435761u + t0 : words32[wi + 1]) : 0u;  // dbg: no loads in the loop
+      nxt = (t0 + 16u < nw_scan) ? ((dbg & 16u) ? hi * 2654435761u + t0 : words32[wi + 1]) : 0u;  // dbg: no loads in the loop
       const uint32_t chunk = funnel(hi, lo, shift);
       lo = hi;
 #pragma unroll
@@ -140,6 +191,7 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
 #pragma unroll
         for (int d = 1; d <= W - 1; ++d) match |= (can == ring[(u - d) & 15]);
         ring[u] = match ? INVALID_ID : can;
+        bgc.kmer3(id, t0 + (uint32_t)u < nw_all);
         emit(can, !match && t0 + (uint32_t)u < nw);
       }
     }
@@ -163,14 +215,17 @@ struct DirectEmit {
   }
 };
 
-template <int W, bool BOTH>
+template <int W, bool BOTH, bool BG>
 __global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__ words32,
                                                     const uint64_t* __restrict__ items, uint32_t n_items,
                                                     uint32_t* __restrict__ hist,
                                                     unsigned long long* __restrict__ ltot,
-                                                    uint32_t* __restrict__ defer) {
+                                                    uint32_t* __restrict__ defer, uint32_t* __restrict__ bg_partials) {
+  bg_begin<BG>();
+  if (BG) __syncthreads();
   DirectEmit e{hist};
-  scan_items<W, BOTH>(words32, items, n_items, ltot, defer, e);
+  scan_items<W, BOTH, BG>(words32, items, n_items, ltot, defer, e);
+  bg_end<BG>(bg_partials);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -305,21 +360,24 @@ struct ScatterEmit {
   }
 };
 
-template <int W, bool BOTH, int NBITS>
+template <int W, bool BOTH, int NBITS, bool BG>
 __global__ __launch_bounds__(256) void count_scatter_kernel(const uint32_t* __restrict__ words32,
                                                             const uint64_t* __restrict__ items, uint32_t n_items,
                                                             uint16_t* __restrict__ keys, uint32_t slice_cap,
                                                             uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
                                                             unsigned long long* __restrict__ ltot,
-                                                            uint32_t* __restrict__ defer, uint32_t dbg) {
+                                                            uint32_t* __restrict__ defer, uint32_t dbg,
+                                                            uint32_t* __restrict__ bg_partials) {
   static_assert(2 * W - NBITS == PAYLOAD_BITS, "payload must be 15 bits");
   ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
   for (uint32_t i = threadIdx.x; i < 4u * (1u << NBITS); i += blockDim.x) (&sh.fill[0][0])[i] = 0;
+  bg_begin<BG>();
   __syncthreads();
   ScatterEmit<W, NBITS> e{keys, slice_cap, gridDim.x * 4u, slice_fill, hist, threadIdx.x >> 6, threadIdx.x & 63u,
                        blockIdx.x * 4u + (threadIdx.x >> 6), 0u, dbg};
-  scan_items<W, BOTH>(words32, items, n_items, ltot, defer, e, dbg);
+  scan_items<W, BOTH, BG>(words32, items, n_items, ltot, defer, e, dbg);
   e.drain();
+  bg_end<BG>(bg_partials);
 }
 
 // One workgroup = 16 waves = part of one bucket: waves walk the (bucket, producer-wave) slices of their share.
@@ -510,6 +568,50 @@ __global__ void bg_finish_kernel(const unsigned long long* __restrict__ raw, uns
   if (t < 64) out[20 + t] = raw[t];
 }
 
+// fused K1b: block partials (little-endian 3-mer digits) -> (n1 | n2 | n3) in BaMM order
+__global__ void bg_finish_fused_kernel(const uint32_t* __restrict__ partials, uint32_t n_blocks,
+                                       unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long raw[84];
+  __shared__ unsigned long long n3[64];
+  __shared__ unsigned long long n2[16];
+  __shared__ unsigned long long part[12][84];
+  const int t = threadIdx.x;
+  {  // 12 strands of 84 threads each sum every 12th block; fixed order -> deterministic
+    const int bin = t % 84, strand = t / 84;
+    if (strand < 12) {
+      unsigned long long s = 0;
+      for (uint32_t b = strand; b < n_blocks; b += 12) s += partials[(size_t)b * 84 + bin];
+      part[strand][bin] = s;
+    }
+  }
+  __syncthreads();
+  if (t < 84) {
+    unsigned long long s = 0;
+    for (int k = 0; k < 12; ++k) s += part[k][t];
+    raw[t] = s;
+  }
+  __syncthreads();
+  if (t < 64) {  // t = BaMM index d0*16 + d1*4 + d2 (d0 oldest)
+    const int d0 = t >> 4, d1 = (t >> 2) & 3, d2 = t & 3;
+    n3[t] = raw[d0 | (d1 << 2) | (d2 << 4)];
+    out[20 + t] = n3[t];
+  }
+  __syncthreads();
+  if (t < 16) {  // t = a*4 + b
+    const int a = t >> 2, b = t & 3;
+    unsigned long long s = raw[68 + (a | (b << 2))];
+    for (int c = 0; c < 4; ++c) s += n3[c * 16 + t];
+    n2[t] = s;
+    out[4 + t] = s;
+  }
+  __syncthreads();
+  if (t < 4) {
+    unsigned long long s = raw[64 + t];
+    for (int b = 0; b < 4; ++b) s += n2[b * 4 + t];
+    out[t] = s;
+  }
+}
+
 // BackgroundModel::calculateV (src/shared/BackgroundModel.cpp:490-530), one thread, float32 in the
 // reference's order.  Counts are converted integer -> float with round-to-nearest (the reference's
 // `int` counters overflow beyond 2^31 bases; below that the results are bit-identical).
@@ -588,25 +690,54 @@ __global__ __launch_bounds__(256) void synth_items_kernel(uint64_t n_seq, uint32
   }
 }
 
-template <int W>
-int launch_direct_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items) {
-  const uint32_t* w32 = (const uint32_t*)ctx->d_words;
-  const uint32_t blocks_needed = (n_items + 255) / 256;
-  const uint32_t max_blocks = (uint32_t)ctx->num_cu * 8u;
-  const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
-  unsigned long long* lt = (unsigned long long*)d_ltot;
-  if (both)
-    hipLaunchKernelGGL((count_kernel<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, w32, ctx->d_items, n_items,
-                       d_counts, lt, ctx->d_defer);
-  else
-    hipLaunchKernelGGL((count_kernel<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, w32, ctx->d_items, n_items,
-                       d_counts, lt, ctx->d_defer);
+// kernel launch with the (BOTH, BG) template bits chosen at run time
+#define PENGK_LAUNCH_BB(KERNEL, TARGS, both, bg, grid, block, ...)                                              \
+  do {                                                                                                         \
+    if (both) {                                                                                                \
+      if (bg) hipLaunchKernelGGL((KERNEL<TARGS(true, true)>), grid, block, 0, ctx->stream, __VA_ARGS__);        \
+      else hipLaunchKernelGGL((KERNEL<TARGS(true, false)>), grid, block, 0, ctx->stream, __VA_ARGS__);          \
+    } else {                                                                                                   \
+      if (bg) hipLaunchKernelGGL((KERNEL<TARGS(false, true)>), grid, block, 0, ctx->stream, __VA_ARGS__);       \
+      else hipLaunchKernelGGL((KERNEL<TARGS(false, false)>), grid, block, 0, ctx->stream, __VA_ARGS__);         \
+    }                                                                                                          \
+  } while (0)
+
+// block partials of the fused K1b (84 uint32 per block of the scan grid)
+int bg_partials_buffer(pengk_ctx* ctx, uint32_t blocks, uint32_t** out) {
+  int rc = ensure_scratch(ctx, &ctx->d_bg_partials, &ctx->bg_partials_bytes, (size_t)blocks * 84 * sizeof(uint32_t));
+  *out = (uint32_t*)ctx->d_bg_partials;
+  return rc;
+}
+
+int bg_finish_fused(pengk_ctx* ctx, uint32_t blocks, uint64_t* d_bg) {
+  hipLaunchKernelGGL(bg_finish_fused_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)ctx->d_bg_partials, blocks,
+                     (unsigned long long*)d_bg);
   PENGK_HIP(hipGetLastError());
   return PENGK_OK;
 }
 
 template <int W>
-int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items) {
+int launch_direct_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items, uint64_t* d_bg) {
+  const uint32_t* w32 = (const uint32_t*)ctx->d_words;
+  const uint32_t blocks_needed = (n_items + 255) / 256;
+  const uint32_t max_blocks = (uint32_t)ctx->num_cu * 8u;
+  const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
+  unsigned long long* lt = (unsigned long long*)d_ltot;
+  uint32_t* bgp = nullptr;
+  if (d_bg) {
+    int rc = bg_partials_buffer(ctx, blocks, &bgp);
+    if (rc) return rc;
+  }
+#define TA_DIRECT(B, G) W, B, G
+  PENGK_LAUNCH_BB(count_kernel, TA_DIRECT, both, d_bg != nullptr, dim3(blocks), dim3(256), w32, ctx->d_items, n_items, d_counts,
+                  lt, ctx->d_defer, bgp);
+#undef TA_DIRECT
+  PENGK_HIP(hipGetLastError());
+  return d_bg ? bg_finish_fused(ctx, blocks, d_bg) : PENGK_OK;
+}
+
+template <int W>
+int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items, uint64_t* d_bg) {
   constexpr int NBITS = 2 * W - PAYLOAD_BITS;
   constexpr uint32_t NB = 1u << NBITS;
   const uint32_t np = 1u << (2 * W);
@@ -635,13 +766,20 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   PENGK_HIP(hipMemsetAsync(ctx->d_count_aux, 0, aux_need, ctx->stream));
   unsigned long long* lt = (unsigned long long*)d_ltot;
   uint16_t* keys = (uint16_t*)ctx->d_keys;
-  if (both)
-    hipLaunchKernelGGL((count_scatter_kernel<W, true, NBITS>), dim3(blocks), dim3(256), 0, ctx->stream, w32, ctx->d_items,
-                       n_items, keys, slice_cap, slice_fill, d_counts, lt, ctx->d_defer, (uint32_t)ctx->debug_flags);
-  else
-    hipLaunchKernelGGL((count_scatter_kernel<W, false, NBITS>), dim3(blocks), dim3(256), 0, ctx->stream, w32, ctx->d_items,
-                       n_items, keys, slice_cap, slice_fill, d_counts, lt, ctx->d_defer, (uint32_t)ctx->debug_flags);
+  uint32_t* bgp = nullptr;
+  if (d_bg) {
+    rc = bg_partials_buffer(ctx, blocks, &bgp);
+    if (rc) return rc;
+  }
+#define TA_SCATTER(B, G) W, B, NBITS, G
+  PENGK_LAUNCH_BB(count_scatter_kernel, TA_SCATTER, both, d_bg != nullptr, dim3(blocks), dim3(256), w32, ctx->d_items, n_items,
+                  keys, slice_cap, slice_fill, d_counts, lt, ctx->d_defer, (uint32_t)ctx->debug_flags, bgp);
+#undef TA_SCATTER
   PENGK_HIP(hipGetLastError());
+  if (d_bg) {
+    rc = bg_finish_fused(ctx, blocks, d_bg);
+    if (rc) return rc;
+  }
   // pass B: one 1024-thread workgroup per CU (128 KiB of LDS), bpb workgroups per bucket
   static bool attr_set = false;
   if (!attr_set) {
@@ -664,19 +802,22 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
 }
 
 template <int W>
-int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) {
+int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg) {
   const uint32_t n_items = (uint32_t)ctx->n_items;
-  if (n_items == 0) return PENGK_OK;
+  if (n_items == 0) {
+    if (d_bg) PENGK_HIP(hipMemsetAsync(d_bg, 0, 84 * sizeof(uint64_t), ctx->stream));
+    return PENGK_OK;
+  }
   int impl = ctx->count_impl;
   constexpr bool can_partition = (W == 8 || W == 10);
   if (impl == 0) impl = can_partition ? 2 : 1;
   if (impl == 2 && !can_partition) return fail(PENGK_ERR_UNSUPPORTED, "partitioned count is built for W = 8 and 10 only");
   int rc;
   if constexpr (can_partition) {
-    rc = impl == 2 ? launch_partition_w<W>(ctx, both, d_counts, d_ltot, n_items)
-                   : launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items);
+    rc = impl == 2 ? launch_partition_w<W>(ctx, both, d_counts, d_ltot, n_items, d_bg)
+                   : launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items, d_bg);
   } else {
-    rc = launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items);
+    rc = launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items, d_bg);
   }
   if (rc) return rc;
   hipLaunchKernelGGL(count_fixup_kernel, dim3(64), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->d_words, ctx->d_items, W,
@@ -687,7 +828,7 @@ int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_lto
 
 }  // namespace
 
-int launch_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) {
+int launch_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg) {
   const int W = ctx->W;
   const size_t np = (size_t)1 << (2 * W);
   // defer list: counter + one slot per item
@@ -704,12 +845,12 @@ int launch_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot)
   PENGK_HIP(hipMemsetAsync(d_counts, 0, np * sizeof(uint32_t), ctx->stream));
   PENGK_HIP(hipMemsetAsync(d_ltot, 0, sizeof(uint64_t), ctx->stream));
   switch (W) {
-    case 4: return launch_count_w<4>(ctx, both, d_counts, d_ltot);
-    case 6: return launch_count_w<6>(ctx, both, d_counts, d_ltot);
-    case 8: return launch_count_w<8>(ctx, both, d_counts, d_ltot);
-    case 10: return launch_count_w<10>(ctx, both, d_counts, d_ltot);
-    case 12: return launch_count_w<12>(ctx, both, d_counts, d_ltot);
-    case 14: return launch_count_w<14>(ctx, both, d_counts, d_ltot);
+    case 4: return launch_count_w<4>(ctx, both, d_counts, d_ltot, d_bg);
+    case 6: return launch_count_w<6>(ctx, both, d_counts, d_ltot, d_bg);
+    case 8: return launch_count_w<8>(ctx, both, d_counts, d_ltot, d_bg);
+    case 10: return launch_count_w<10>(ctx, both, d_counts, d_ltot, d_bg);
+    case 12: return launch_count_w<12>(ctx, both, d_counts, d_ltot, d_bg);
+    case 14: return launch_count_w<14>(ctx, both, d_counts, d_ltot, d_bg);
     default: return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
   }
 }

@@ -26,6 +26,8 @@ struct pengk_ctx {
   size_t em_partials_bytes = 0;
   void* d_misc = nullptr;  // small staging buffer
   size_t misc_bytes = 0;
+  void* d_bg_partials = nullptr;  // fused K1b: per-block bins
+  size_t bg_partials_bytes = 0;
   void* d_keys = nullptr;  // partitioned count: bucket regions of 16-bit keys
   size_t keys_bytes = 0;
   void* d_count_aux = nullptr;  // partitioned count: cursors + bucket-major table
@@ -74,7 +76,7 @@ __host__ __device__ inline uint32_t revcomp32(uint32_t id, int W) {
 }
 
 // launchers implemented in the .hip files
-int launch_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot);
+int launch_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg /* may be NULL */);
 int launch_mirror(pengk_ctx* ctx, int W, uint32_t* d_counts);
 int launch_bg_count(pengk_ctx* ctx, uint64_t* d_bg);
 int launch_bg_model(pengk_ctx* ctx, const uint64_t* d_bg, int K, const float* h_alpha, float* d_V);

@@ -223,6 +223,45 @@ def test_device_bg_count_matches_packer_and_oracle(ctx, golden_dir):
         assert np.array_equal(got, po.bg_counts(codes, offs, 2))
 
 
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("W,M", [(10, 64), (10, 0), (8, 64), (6, 0)])
+def test_fused_bg_count(ctx, golden_dir, W, M, impl):
+    """pengk_count_bg: the 3-mer bins collected inside the count scan == the packer's / oracle's counts,
+    and the count table is unchanged.  M = 64 splits runs (continuing items must not recount their prologue)."""
+    if impl == 2 and W not in (8, 10):
+        pytest.skip("partitioned count is built for W = 8, 10")
+    codes, offs = po.read_fasta(os.path.join(golden_dir, "MafK.fasta"))
+    codes, offs = codes[:offs[600]], offs[:601]
+    p = pk.Packed(codes, offs, W, M)
+    ctx.upload(p)
+    ctx.set_option("count_impl", impl)
+    try:
+        counts, lt, bg = ctx.count_bg(False)
+        want, ltot = po.count(codes, offs, W, False)
+        assert int(lt.to_host()[0]) == ltot
+        assert np.array_equal(counts.to_host().astype(np.uint64), want)
+        assert np.array_equal(bg.to_host().astype(np.int64), po.bg_counts(codes, offs, 2))
+    finally:
+        ctx.set_option("count_impl", 0)
+
+
+def test_fused_bg_count_with_deferred_items(ctx):
+    """low-complexity runs split into items: deferred items still contribute their bases to the fused bins."""
+    codes, offs = low_complexity_set(11, 48, 900)
+    keep = [i for i in range(48) if i % 6 != 3]  # drop the sequences with N (bg recount needs whole runs)
+    codes = np.concatenate([codes[offs[i]:offs[i + 1]] for i in keep])
+    offs = np.arange(len(keep) + 1, dtype=np.int64) * 900
+    p = pk.Packed(codes, offs, 10, 64)
+    assert p.all_whole == 1
+    ctx.upload(p)
+    counts, lt, bg = ctx.count_bg(True)
+    assert ctx.info("deferred_items") > 0
+    ctx.mirror(10, counts)
+    want, ltot = po.count(codes, offs, 10, True)
+    assert np.array_equal(counts.to_host().astype(np.uint64), want)
+    assert np.array_equal(bg.to_host().astype(np.int64), po.bg_counts(codes, offs, 2))
+
+
 def test_synthetic_generator_matches_cpu(ctx):
     """pengk_synth_sequences == the counter-based generator of SURVEY.md 8d (oracle po_synth)."""
     n, L, W = 3000, 200, 10
