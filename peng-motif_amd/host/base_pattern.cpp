@@ -1,0 +1,189 @@
+// BasePattern -- host mirror; the constructor is the hot path: pack -> count (K1) -> mirror -> sweep
+// (K2+K3) on the device, then one copy of each table into the host arrays the public getters expose
+// (replaces src/base_pattern.cpp:17-64 and everything it calls, :231-441).
+#include "base_pattern.h"
+
+#include <algorithm>
+#include <cmath>
+#include <iomanip>
+#include <iostream>
+
+#include "utils.h"
+
+using pengk_host::check;
+using pengk_host::context;
+
+BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, const int max_k, SequenceSet* sequence_set,
+                         BackgroundModel* bg) {
+  alphabet_size = Alphabet::getSize();
+  strand = s;
+  background_model = bg;
+  init(pattern_length);
+  number_patterns = factor[pattern_length];
+  n_sequences = sequence_set->getN();
+  this->k = k;
+  this->max_k = std::max(k, max_k);
+  const int W = (int)pattern_length;
+  const int both = strand == Strand::BOTH_STRANDS;
+  const size_t NP = number_patterns;
+
+  // ---- sequences -> 2-bit stream + scan items (host packer resolves the N / skip scan rule) ----------
+  std::vector<uint8_t> codes;
+  std::vector<int64_t> offs(1, 0);
+  for (Sequence* q : sequence_set->sequences()) {
+    codes.insert(codes.end(), q->getSequence(), q->getSequence() + q->getL());
+    offs.push_back((int64_t)codes.size());
+  }
+  pengk_packed pk;
+  check(pengk_pack(codes.data(), offs.data(), (int64_t)offs.size() - 1, W, 0, &pk), "pengk_pack");
+  pengk_host::DeviceBuffer<uint64_t> d_words(pk.n_words), d_items(pk.n_items + 1), d_ltot(1);
+  d_words.upload(pk.words, pk.n_words);
+  if (pk.n_items) d_items.upload(pk.items, pk.n_items);
+  check(pengk_set_sequences(context(), d_words.get(), pk.n_words, d_items.get(), pk.n_items, W, pk.item_windows,
+                            pk.max_bin_bound, pk.all_whole),
+        "pengk_set_sequences");
+  check(pengk_set_option(context(), "n_windows_hint", (int64_t)pk.n_windows), "pengk_set_option");
+  pengk_packed_free(&pk);
+
+  // ---- K1 count (+ twin copy), K2+K3 sweep ---------------------------------------------------------------
+  d_counts.resize(NP);
+  check(pengk_count(context(), both, d_counts.get(), d_ltot.get()), "pengk_count");
+  if (both) check(pengk_mirror_counts(context(), W, d_counts.get()), "pengk_mirror_counts");
+
+  float hV[84] = {0};
+  for (int o = 0, at = 0; o <= 2; at += 1 << (2 * (o + 1)), ++o)
+    if (o <= bg->getOrder())
+      for (int y = 0; y < (1 << (2 * (o + 1))); ++y) hV[at + y] = bg->getV()[o][y];
+  pengk_host::DeviceBuffer<float> d_V(84), d_logp(NP), d_z(NP);
+  d_V.upload(hV, 84);
+  d_bgprob.resize((size_t)(this->max_k + 1) * NP);
+  d_expected.resize(NP);
+  check(pengk_pattern_stats(context(), W, both, this->k, this->max_k, d_V.get(), d_ltot.get(), d_counts.get(), d_bgprob.get(),
+                            d_expected.get(), d_logp.get(), d_z.get()),
+        "pengk_pattern_stats");
+
+  // ---- host mirrors behind the raw-pointer getters ---------------------------------------------------------
+  pattern_counter = new size_t[NP];
+  {
+    std::vector<uint32_t> c32(NP);
+    d_counts.download(c32.data(), NP);
+    for (size_t i = 0; i < NP; ++i) pattern_counter[i] = c32[i];
+  }
+  uint64_t lt = 0;
+  d_ltot.download(&lt, 1);
+  ltot = lt;
+  pattern_bg_probabilities = new float*[this->max_k + 1];
+  for (int o = 0; o <= this->max_k; ++o) {
+    pattern_bg_probabilities[o] = new float[NP];
+    d_bgprob.download(pattern_bg_probabilities[o], NP, (size_t)o * NP);
+  }
+  expected_counts = new float[NP];
+  pattern_logp = new float[NP];
+  pattern_zscore = new float[NP];
+  d_expected.download(expected_counts, NP);
+  d_logp.download(pattern_logp, NP);
+  d_z.download(pattern_zscore, NP);
+}
+
+BasePattern::~BasePattern() {
+  delete[] pattern_counter;
+  for (int o = 0; o <= max_k; ++o) delete[] pattern_bg_probabilities[o];
+  delete[] pattern_bg_probabilities;
+  delete[] pattern_logp;
+  delete[] pattern_zscore;
+  delete[] expected_counts;
+  delete[] factor;
+}
+
+void BasePattern::init(size_t pattern_length) {
+  this->pattern_length = pattern_length;
+  factor = new size_t[pattern_length + 1];
+  for (size_t i = 0; i <= pattern_length; ++i) factor[i] = (size_t)1 << (2 * i);
+}
+
+std::string BasePattern::toString(size_t pattern_id) {
+  std::string out;
+  for (size_t p = 0; p < pattern_length; ++p) out += Alphabet::getBase((uint8_t)(getNucleotideAtPos(pattern_id, p) + 1));
+  return out;
+}
+
+// reverse the digit order and complement every digit (3 - d)
+size_t BasePattern::getRevCompId(const size_t pattern_id) {
+  size_t r = 0, x = pattern_id;
+  for (size_t p = 0; p < pattern_length; ++p) {
+    r = (r << 2) | (3 - (x & 3));
+    x >>= 2;
+  }
+  return r;
+}
+
+size_t BasePattern::getFastRevCompId(const size_t pattern_id) { return getRevCompId(pattern_id); }
+
+size_t BasePattern::baseId2IUPACId(const size_t base_pattern) {
+  size_t id = 0;
+  for (size_t p = 0; p < pattern_length; ++p) id += getNucleotideAtPos(base_pattern, p) * IUPACPattern::iupac_factor[p];
+  return id;
+}
+
+float BasePattern::getExpCountFraction(const size_t pattern, const size_t pseudo_expected_pattern_counts) {
+  return (expected_counts[pattern] + (float)pseudo_expected_pattern_counts) / (float)pattern_counter[pattern];
+}
+
+float BasePattern::getMutualInformationScore(const size_t pattern) {
+  const unsigned int observed = (unsigned int)pattern_counter[pattern];
+  return mutual_information_score((float)observed, expected_counts[pattern], (unsigned int)n_sequences);
+}
+
+float BasePattern::getOptimizationScore(const OPTIMIZATION_SCORE score_type, const size_t pattern,
+                                        const size_t pseudo_expected_pattern_counts) {
+  switch (score_type) {
+    case OPTIMIZATION_SCORE::kLogPval: return getLogPval(pattern);
+    case OPTIMIZATION_SCORE::kExpCounts: return getExpCountFraction(pattern, pseudo_expected_pattern_counts);
+    case OPTIMIZATION_SCORE::MutualInformation: return getMutualInformationScore(pattern);
+  }
+  std::cerr << "Error: unknown score type!" << std::endl;
+  exit(1);
+}
+
+// Seeds in descending z order.  The same non-stable std::sort over the same bit-identical z array as the
+// reference (src/base_pattern.cpp:458) decides which reverse-complement twin of a tie comes first.
+std::vector<size_t> BasePattern::select_base_patterns(const float zscore_threshold, const size_t count_threshold,
+                                                      bool single_stranded, bool filter_neighbors) {
+  std::vector<size_t> selected;
+  std::vector<char> seen(number_patterns, 0);
+  size_t* order = new size_t[number_patterns];
+  for (size_t i = 0; i < number_patterns; ++i) order[i] = i;
+  std::sort(order, order + number_patterns, sort_indices(pattern_zscore));
+  for (size_t r = 0; r < number_patterns; ++r) {
+    const size_t x = order[r];
+    if (pattern_zscore[x] < zscore_threshold) break;
+    if (pattern_counter[x] < count_threshold) continue;
+    if (seen[x] || (!single_stranded && seen[getFastRevCompId(x)])) continue;
+    selected.push_back(x);
+    seen[x] = 1;
+    if (filter_neighbors)
+      for (size_t p = 0; p < pattern_length; ++p) {
+        const size_t masked = x & ~((size_t)3 << (2 * p));
+        for (size_t c = 0; c < 4; ++c) seen[masked | (c << (2 * p))] = 1;
+      }
+  }
+  delete[] order;
+  return selected;
+}
+
+std::vector<size_t> BasePattern::generate_double_stranded_em_optimization_patterns() {
+  std::vector<size_t> out;
+  for (size_t x = 0; x < number_patterns; ++x)
+    if (x <= getFastRevCompId(x)) out.push_back(x);
+  return out;
+}
+
+void BasePattern::print_patterns(std::vector<size_t> patterns) {
+  std::cout << std::setw(15) << "pattern" << "\t" << std::setw(15) << "observed" << "\t" << std::setw(15) << "enrichment"
+            << "\t" << std::setw(15) << "zscore" << std::endl
+            << std::endl;
+  std::cout << std::fixed << std::setprecision(2);
+  for (size_t x : patterns)
+    std::cout << std::setw(15) << toString(x) << "\t" << std::setw(15) << pattern_counter[x] << "\t" << std::setw(15)
+              << (pattern_counter[x] / expected_counts[x]) << "\t" << std::setw(15) << pattern_zscore[x] << std::endl;
+}

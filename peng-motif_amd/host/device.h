@@ -1,0 +1,51 @@
+// device.h -- the one pengk context of the process and RAII device buffers for the host mirror.
+// Every hot loop of BasePattern / IUPACPattern / Peng goes through include/pengk.h; there is no CPU
+// fallback: a failing call prints pengk_last_error() and exits like the reference's error paths do.
+#ifndef PENGK_HOST_DEVICE_H_
+#define PENGK_HOST_DEVICE_H_
+
+#include <cstddef>
+#include <cstdint>
+
+#include "pengk.h"
+
+namespace pengk_host {
+
+pengk_ctx* context();           // created on first use on Global::device
+void shutdown();
+void check(int rc, const char* what);
+
+template <class T>
+class DeviceBuffer {
+ public:
+  DeviceBuffer() = default;
+  explicit DeviceBuffer(size_t n) { resize(n); }
+  ~DeviceBuffer() { release(); }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  void resize(size_t n) {
+    release();
+    n_ = n;
+    void* p = nullptr;
+    check(pengk_malloc(context(), (n ? n : 1) * sizeof(T), &p), "pengk_malloc");
+    p_ = (T*)p;
+  }
+  void release() {
+    if (p_) check(pengk_free(context(), p_), "pengk_free");
+    p_ = nullptr;
+    n_ = 0;
+  }
+  void upload(const T* h, size_t n) { check(pengk_memcpy_h2d(context(), p_, h, n * sizeof(T)), "pengk_memcpy_h2d"); }
+  void download(T* h, size_t n, size_t offset = 0) const {
+    check(pengk_memcpy_d2h(context(), h, p_ + offset, n * sizeof(T)), "pengk_memcpy_d2h");
+  }
+  T* get() const { return p_; }
+  size_t size() const { return n_; }
+
+ private:
+  T* p_ = nullptr;
+  size_t n_ = 0;
+};
+
+}  // namespace pengk_host
+#endif

@@ -1,0 +1,51 @@
+// peng_motif -- command-line entry of the MI355X mirror: same flags, stdout trace, MEME / JSON output
+// and exit codes as the reference's src/main.cpp; the hot loops run on the GPU through libpengk.
+#include <algorithm>
+#include <iostream>
+
+#include "Global.h"
+#include "device.h"
+#include "iupac_pattern.h"
+#include "peng.h"
+
+int main(int nargs, char** args) {
+  Global::init(nargs, args);
+  pengk_host::context();  // fail early (exit 1) when no gfx950 device is present: there is no CPU path
+
+  const int bg_model_order = std::max(Global::bgModelOrder, Global::maxOptBgModelOrder);
+  BackgroundModel* bgModel =
+      new BackgroundModel(*Global::backgroundSequenceSet, bg_model_order, Global::bgModelAlpha, Global::interpolateBG);
+
+  Peng peng(Global::strand, Global::bgModelOrder, Global::maxOptBgModelOrder, Global::inputSequenceSet, bgModel);
+
+  PengParameters params;
+  params.max_pattern_length = Global::patternLength;
+  params.zscore_threshold = Global::zscoreThreshold;
+  params.count_threshold = Global::countThreshold;
+  params.pseudo_counts = Global::pseudoCounts;
+  params.opt_score_type = Global::optScoreType;
+  params.use_em = Global::useEm;
+  params.em_saturation_factor = Global::emSaturationFactor;
+  params.em_min_threshold = Global::emMinThreshold;
+  params.em_max_iterations = Global::emMaxIterations;
+  params.use_merging = Global::useMerging;
+  params.bit_factor_merge_threshold = Global::mergeBitfactorThreshold;
+  params.max_merged_length = Global::max_merged_length;
+  params.adv_pwm = Global::useAdvPWM;
+  params.enrich_pseudocount_factor = Global::enrich_pseudocount_factor;
+  params.minimum_processed_motifs = Global::minimum_processed_motifs;
+  params.filter_neighbors = Global::filter_neighbors;
+  params.max_optimized_patterns = Global::maximum_optimized_patterns;
+
+  std::vector<IUPACPattern*> result;
+  peng.process(params, result);
+  peng.filter_redundancy(Global::mergeBitfactorThreshold, result);
+  if (Global::outputFilename) peng.printShortMeme(result, Global::outputFilename, bgModel);
+  if (Global::jsonFilename) peng.printJson(result, Global::jsonFilename, VERSION_NUMBER, bgModel);
+
+  for (IUPACPattern* p : result) delete p;
+  delete bgModel;
+  Global::destruct();
+  pengk_host::shutdown();
+  return 0;
+}

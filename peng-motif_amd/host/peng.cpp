@@ -1,0 +1,389 @@
+// Peng -- host mirror of the reference's orchestration (src/peng.cpp); see peng.h.
+#include "peng.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+
+#include "base_pattern.h"
+#include "device.h"
+#include "iupac_alphabet.h"
+#include "utils.h"
+
+namespace {
+void print_status(const std::string& header, bool leading_newline = true) {
+  if (leading_newline) std::cout << std::endl;
+  std::cout << "[STATUS] " << header << ":" << std::endl;
+}
+
+// add epsilon = 10^-precision / (1 - 4 * 10^-precision) to every cell and renormalise; mutates the PWM,
+// so writing MEME and JSON in one run applies it twice (reference behaviour)
+void no_zero_pwm(float** pwm, unsigned rows, unsigned precision) {
+  const float delta = (float)std::pow(10, -static_cast<int>(precision));
+  const float epsilon = delta / (1 - 4 * delta);
+  for (unsigned i = 0; i < rows; ++i)
+    for (unsigned j = 0; j < 4; ++j) pwm[i][j] += epsilon;
+  IUPACPattern::normalize_pwm((int)rows, pwm);
+}
+
+void print_row(IUPACPattern* p, size_t W, float score, bool with_score) {
+  std::cout << "\t" << std::setw(15) << IUPACPattern::toString(p->get_pattern(), W) << "\t" << std::setw(10) << p->get_sites()
+            << "\t" << std::setw(5) << std::setprecision(2) << p->get_sites() / p->getExpectedCounts();
+  if (with_score) std::cout << "\t" << std::setw(10) << std::setprecision(6) << score;
+  std::cout << std::endl;
+}
+}  // namespace
+
+Peng::Peng(Strand s, const int k, const int max_opt_k, SequenceSet* sequence_set, BackgroundModel* bg) {
+  const int max_iupac_pattern_length = (int)(std::log((double)SIZE_MAX) / std::log((double)IUPAC_ALPHABET_SIZE) - 1);
+  alphabet_size = Alphabet::getSize();
+  this->k = k;
+  max_k = std::max(k, max_opt_k);
+  strand = s;
+  n_sequences = sequence_set->getN();
+  IUPACAlphabet::init(Alphabet::getAlphabet());
+  IUPACPattern::init(max_iupac_pattern_length, bg->getV()[0]);
+  bg_model = bg;
+  this->sequence_set = sequence_set;
+}
+
+Peng::~Peng() {}
+
+// ---- EM: all PWMs in one device call (replaces src/peng.cpp:48-197) --------------------------------------
+void Peng::em_optimize_pwms(std::vector<IUPACPattern*>& patterns, BasePattern* base_patterns, float saturation_factor,
+                            float min_em_threshold, int max_iterations, int background_order,
+                            std::vector<IUPACPattern*>& optimized) {
+  const size_t W = base_patterns->getPatternLength();
+  const size_t n = patterns.size();
+  std::vector<float> pw(n * W * 4);
+  for (size_t i = 0; i < n; ++i)
+    for (size_t p = 0; p < W; ++p)
+      for (int a = 0; a < 4; ++a) pw[(i * W + p) * 4 + a] = patterns[i]->get_pwm()[p][a];
+  if (n)
+    pengk_host::check(pengk_em(pengk_host::context(), (int)W, (int64_t)n, pw.data(), saturation_factor, min_em_threshold,
+                               max_iterations, base_patterns->device_counts(), base_patterns->device_bgprob(background_order),
+                               nullptr, nullptr),
+                      "pengk_em");
+  for (size_t i = 0; i < n; ++i) {
+    std::vector<float*> rows(W);
+    for (size_t p = 0; p < W; ++p) rows[p] = &pw[(i * W + p) * 4];
+    IUPACPattern* opt = new IUPACPattern(patterns[i], rows.data());  // renormalises, builds the complement PWM
+    optimized.push_back(opt);
+    const float avg_info = calculate_pwm_info(opt->get_pwm(), (unsigned)W, (unsigned)alphabet_size) / W;
+    std::cout << "em: " << IUPACPattern::toString(patterns[i]->get_pattern(), W) << " -> " << opt->get_pattern_string()
+              << "   [ avg. info: " << std::setprecision(2) << avg_info << " ]" << std::endl;
+  }
+}
+
+// ---- redundancy filter on the final list (src/peng.cpp:199-235) --------------------------------------------
+void Peng::filter_redundancy(const float merge_bit_factor_threshold, std::vector<IUPACPattern*>& pats) {
+  std::sort(pats.begin(), pats.end(), sort_IUPAC_patterns);
+  std::vector<char> drop(pats.size(), 0);
+  for (size_t i = 0; i < pats.size(); ++i) {
+    if (drop[i]) continue;
+    for (size_t j = i + 1; j < pats.size(); ++j) {
+      if (drop[j] || pats[i]->get_pattern_length() != pats[j]->get_pattern_length()) continue;
+      const int L = (int)pats[i]->get_pattern_length();
+      const float s1 = IUPACPattern::calculate_s(pats[i]->get_pwm(), pats[j]->get_pwm(), bg_model->getV()[0], 0, 0, L);
+      const float s2 = IUPACPattern::calculate_s(pats[i]->get_comp_pwm(), pats[j]->get_pwm(), bg_model->getV()[0], 0, 0, L);
+      const float threshold = merge_bit_factor_threshold * L;
+      if (s1 > threshold || s2 > threshold) {
+        drop[j] = 1;
+        break;  // the reference stops scanning partners of i after the first hit
+      }
+    }
+  }
+  std::vector<IUPACPattern*> kept;
+  for (size_t i = 0; i < pats.size(); ++i) {
+    if (drop[i]) delete pats[i];
+    else kept.push_back(pats[i]);
+  }
+  pats.swap(kept);
+}
+
+// ---- greedy pairwise merging (src/peng.cpp:237-313) ----------------------------------------------------------
+void Peng::merge_iupac_patterns(const size_t pattern_length, const float threshold_factor, BackgroundModel*,
+                                std::vector<IUPACPattern*>& pats, size_t max_merged_length) {
+  for (;;) {
+    float best_score = -std::numeric_limits<float>::infinity();
+    size_t bi = 0, bj = 0;
+    int best_shift = 0;
+    bool best_comp = false;
+    for (size_t i = 0; i < pats.size(); ++i) {
+      if (pats[i]->getLogPval() > -5) continue;
+      for (size_t j = i + 1; j < pats.size(); ++j) {
+        if (pats[j]->getLogPval() > -5) continue;
+        auto res = IUPACPattern::calculate_S(pats[i], pats[j], strand, bg_model->getV()[0]);
+        if (std::get<0>(res) > best_score) {
+          best_score = std::get<0>(res);
+          bi = i;
+          bj = j;
+          best_shift = std::get<1>(res);
+          best_comp = std::get<2>(res);
+        }
+      }
+    }
+    if (!(best_score > pattern_length * threshold_factor && pats[bi]->get_pattern_length() <= max_merged_length &&
+          pats[bj]->get_pattern_length() <= max_merged_length))
+      return;
+    IUPACPattern* longer = pats[bi];
+    IUPACPattern* shorter = pats[bj];
+    if (longer->get_pattern_length() < shorter->get_pattern_length()) std::swap(longer, shorter);
+    IUPACPattern* merged = new IUPACPattern(longer, shorter, best_comp, bg_model->getV()[0], best_shift);
+    const size_t mlen = merged->get_pattern_length();
+    if (!(mlen <= sequence_set->getMaxL() && mlen <= max_merged_length)) {
+      // the reference keeps looping on the same best pair here (src/peng.cpp:308-310, `continue` with
+      // found_better == false ends its while loop): stop merging
+      delete merged;
+      return;
+    }
+    std::cout << "merge: " << pats[bj]->get_pattern_string() << " + " << pats[bi]->get_pattern_string() << " -> "
+              << merged->get_pattern_string() << std::endl;
+    delete pats[bj];
+    delete pats[bi];
+    pats.erase(pats.begin() + bj);
+    pats.erase(pats.begin() + bi);
+    pats.push_back(merged);
+  }
+}
+
+// ---- one pass over pattern length W (src/peng.cpp:322-435) ----------------------------------------------------
+void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupac_patterns) {
+  const double lim11 = std::log((double)SIZE_MAX) / std::log((double)IUPAC_ALPHABET_SIZE) - 1;
+  const double lim4 = std::log((double)SIZE_MAX) / std::log((double)Alphabet::getSize()) - 1;
+  if (params.max_pattern_length > lim11 || params.max_pattern_length > lim4) {
+    std::cerr << "Warning: pattern length too long!" << std::endl;
+    std::cerr << "max pattern length: " << std::max(lim11, lim4) << std::endl;
+    exit(1);
+  }
+  const size_t W = params.max_pattern_length;
+  print_status("Processing kmers of length " + std::to_string(W), false);
+  print_status("Finding overrepresented kmers (base patterns)", false);
+  const int cur_k = std::min((int)W - 1, k), cur_max_k = std::min((int)W - 1, max_k);
+  BasePattern* base = new BasePattern(W, strand, cur_k, cur_max_k, sequence_set, bg_model);
+  size_t* counter = base->getPatternCounter();
+
+  auto seeds = base->select_base_patterns(params.zscore_threshold, params.count_threshold, strand == Strand::PLUS_STRAND,
+                                          params.filter_neighbors);
+  if (seeds.empty()) std::cout << "No overrepresented seed patterns found. Stopping." << std::endl;
+  base->print_patterns(seeds);
+
+  print_status("Optimizing base patterns");
+  std::cout << std::endl;
+  if (seeds.size() > params.max_optimized_patterns) seeds.resize(params.max_optimized_patterns);
+  std::vector<IUPACPattern*> unoptimized;
+  optimize_iupac_patterns(params.opt_score_type, base, seeds, unoptimized, params.enrich_pseudocount_factor);
+  std::cout << std::endl;
+
+  print_status("Filtering degenerated IUPAC patterns");
+  filter_iupac_patterns(W, params.minimum_processed_motifs, unoptimized);
+  for (auto p : unoptimized) std::cout << "selected iupac pattern: " << IUPACPattern::toString(p->get_pattern(), W) << std::endl;
+
+  print_status("Calculating PWMs");
+  for (IUPACPattern* p : unoptimized) {
+    if (params.adv_pwm) {
+      std::cout << "adv pwm: ";
+      p->calculate_adv_pwm(base, params.pseudo_counts, counter, bg_model->getV()[0]);
+    } else {
+      std::cout << "def pwm: ";
+      p->calculate_pwm(base, params.pseudo_counts, counter, bg_model->getV()[0]);
+    }
+    const float avg_info = calculate_pwm_info(p->get_pwm(), (unsigned)W, (unsigned)alphabet_size) / W;
+    std::cout << IUPACPattern::toString(p->get_pattern(), W) << " -> " << p->get_pattern_string()
+              << "   [ avg. info: " << std::setprecision(2) << avg_info << " ]" << std::endl;
+  }
+
+  print_status("Optimizing expectation-maximization / merging patterns");
+  {
+    const int background = max_k > (int)W - 1 ? (int)W - 1 : max_k;
+    std::cout << std::endl << "background order: " << max_k << std::endl;
+    std::vector<IUPACPattern*> optimized;
+    if (params.use_em) {
+      em_optimize_pwms(unoptimized, base, params.em_saturation_factor, params.em_min_threshold, params.em_max_iterations,
+                       background, optimized);
+    } else {
+      optimized = std::move(unoptimized);
+      unoptimized.clear();
+    }
+    if (params.use_merging) {
+      if (W >= (size_t)MIN_MERGE_OVERLAP) {
+        merge_iupac_patterns(W, params.bit_factor_merge_threshold, bg_model, optimized, params.max_merged_length);
+      } else {
+        std::cerr << "Warning: Specified pattern length (" << W << ") is too low for merging!" << std::endl;
+      }
+    }
+    for (IUPACPattern* p : optimized) {
+      p->set_optimization_bg_model_order(max_k);
+      best_iupac_patterns.push_back(p);
+    }
+  }
+  for (IUPACPattern* p : unoptimized) delete p;
+  delete base;
+}
+
+// ---- hill-climb in IUPAC space (src/peng.cpp:437-541) -----------------------------------------------------------
+// Per round all single-letter mutants of the current mother are scored in ONE device launch; the
+// accept/reject decisions then replay in the reference's order (position-major, neighbourhood order)
+// on the same float scores, so the walk is identical.
+void Peng::optimize_iupac_patterns(OPTIMIZATION_SCORE score_type, BasePattern* base_patterns,
+                                   std::vector<size_t>& selected_base_patterns, std::vector<IUPACPattern*>& best_iupac_patterns,
+                                   float enrich_pseudocount_factor) {
+  std::set<size_t> seen, best;
+  const size_t W = base_patterns->getPatternLength();
+  const size_t pseudo_expected = (size_t)(sequence_set->getN() * enrich_pseudocount_factor);
+
+  for (size_t seed : selected_base_patterns) {
+    IUPACPattern* best_mutant = new IUPACPattern(base_patterns->baseId2IUPACId(seed), W);
+    best_mutant->aggregate_attributes_from_basepatterns(base_patterns);
+    float best_score = base_patterns->getOptimizationScore(score_type, seed, pseudo_expected);
+    print_row(best_mutant, W, best_score, true);
+
+    bool found_better = true;
+    while (found_better) {
+      found_better = false;
+      const size_t mother = best_mutant->get_pattern();
+      std::vector<IUPACPattern*> mutants;
+      for (size_t p = 0; p < W; ++p) {
+        const int c = IUPACPattern::getNucleotideAtPos(mother, p);
+        const size_t masked = mother - c * IUPACPattern::iupac_factor[p];
+        for (int r : IUPACAlphabet::similar(c)) mutants.push_back(new IUPACPattern(masked + r * IUPACPattern::iupac_factor[p], W));
+      }
+      IUPACPattern::aggregate_batch(base_patterns, mutants);
+      std::set<size_t> current_seen;
+      for (IUPACPattern* m : mutants) {
+        current_seen.insert(m->get_pattern());
+        const float score = m->getOptimizationScore(score_type, pseudo_expected, (unsigned)n_sequences);
+        if (score < best_score) {
+          delete best_mutant;
+          best_mutant = m;
+          best_score = score;
+          found_better = true;
+          print_row(best_mutant, W, best_score, true);
+        } else {
+          delete m;
+        }
+      }
+      if (seen.count(best_mutant->get_pattern()) == 1) found_better = false;
+      current_seen.erase(best_mutant->get_pattern());
+      seen.insert(current_seen.begin(), current_seen.end());
+    }
+
+    if (best.count(best_mutant->get_pattern()) == 0 && seen.count(best_mutant->get_pattern()) == 0) {
+      best_iupac_patterns.push_back(best_mutant);
+      best.insert(best_mutant->get_pattern());
+      seen.insert(best_mutant->get_pattern());
+      std::cout << "optimization: " << base_patterns->toString(seed) << " -> "
+                << IUPACPattern::toString(best_mutant->get_pattern(), W) << std::endl
+                << std::endl;
+    } else {
+      std::cout << "optimization: " << base_patterns->toString(seed) << " removed" << '\t' << std::endl << std::endl;
+      delete best_mutant;
+    }
+  }
+
+  std::cout << std::setw(15) << "pattern" << "\t" << std::setw(15) << "observed" << "\t" << std::setw(15) << "enrichment"
+            << "\t" << std::setw(15) << "zscore" << std::endl
+            << std::endl;
+  std::cout << std::fixed << std::setprecision(2);
+  for (auto p : best_iupac_patterns)
+    std::cout << std::setw(15) << IUPACPattern::toString(p->get_pattern(), W) << "\t" << std::setw(15) << p->get_sites() << "\t"
+              << std::setw(15) << (p->get_sites() / p->getExpectedCounts()) << "\t" << std::setw(15) << p->getZscore()
+              << std::endl;
+}
+
+// ---- drop near-all-N patterns and weak ones (src/peng.cpp:543-599) ------------------------------------------------
+void Peng::filter_iupac_patterns(size_t pattern_length, size_t minimum_retained_motifs, std::vector<IUPACPattern*>& pats) {
+  std::vector<IUPACPattern*> kept, dropped;
+  for (IUPACPattern* p : pats) {
+    size_t n_wild = 0;
+    for (size_t q = 0; q < pattern_length; ++q)
+      if (IUPACPattern::getNucleotideAtPos(p->get_pattern(), q) == (int)IUPAC_Alphabet::N) ++n_wild;
+    (pattern_length - n_wild <= 3 ? dropped : kept).push_back(p);
+  }
+  std::sort(kept.begin(), kept.end(), sort_IUPAC_patterns);
+  float min_pvalue = -5.f;
+  if (!kept.empty()) min_pvalue = std::min(-5.f, kept[0]->getLogPval() * 0.2f);
+  pats.clear();
+  for (size_t i = 0; i < kept.size(); ++i) {
+    if (kept[i]->getLogPval() < min_pvalue || i < minimum_retained_motifs) pats.push_back(kept[i]);
+    else dropped.push_back(kept[i]);
+  }
+  for (IUPACPattern* p : dropped) delete p;
+}
+
+// ---- writers (src/peng.cpp:602-728) ----------------------------------------------------------------------------------
+void Peng::printShortMeme(std::vector<IUPACPattern*>& pats, const std::string output_filename, BackgroundModel* bg) {
+  const unsigned PRECISION = 8;
+  std::sort(pats.begin(), pats.end(), sort_IUPAC_patterns);
+  std::ofstream out(output_filename);
+  if (!out.is_open()) {
+    std::cerr << "Unable to open output file (" << output_filename << ")!";
+    return;
+  }
+  const char* alphabet = Alphabet::getAlphabet();
+  out << "MEME version 4" << std::endl << std::endl;
+  out << "ALPHABET= " << alphabet << std::endl << std::endl;
+  out << "Background letter frequencies" << std::endl;
+  for (size_t i = 0; i < strlen(alphabet); ++i) out << (i ? " " : "") << alphabet[i] << " " << bg->getV()[0][i];
+  out << std::endl << std::endl;
+  for (IUPACPattern* p : pats) {
+    out << "MOTIF " << p->get_pattern_string() << std::endl;
+    out << "letter-probability matrix:" << " alength= " << 4 << " w= " << p->get_pattern_length() << " nsites= " << p->get_sites()
+        << " bg_prob= " << p->get_bg_p() << " opt_bg_order= " << p->get_optimization_bg_model_order()
+        << " log(Pval)= " << p->getLogPval() << std::endl;
+    float** pwm = p->get_pwm();
+    no_zero_pwm(pwm, (unsigned)p->get_pattern_length(), PRECISION);
+    for (size_t w = 0; w < p->get_pattern_length(); ++w) {
+      for (size_t a = 0; a < 4; ++a) out << (a ? " " : "") << std::fixed << std::setprecision(PRECISION) << pwm[w][a];
+      out << std::endl;
+    }
+    out << std::endl;
+  }
+}
+
+void Peng::printJson(std::vector<IUPACPattern*>& pats, const std::string output_filename, const std::string,
+                     BackgroundModel* bg) {
+  const unsigned PRECISION = 8;
+  std::sort(pats.begin(), pats.end(), sort_IUPAC_patterns);
+  std::ofstream out(output_filename);
+  if (!out.is_open()) {
+    std::cerr << "Unable to open output file (" << output_filename << ")!";
+    return;
+  }
+  const char* alphabet = Alphabet::getAlphabet();
+  out << "{" << std::endl;
+  out << "\t\"alphabet\" : \"" << alphabet << "\"," << std::endl;
+  out << "\t\"bg\" : [";
+  for (size_t i = 0; i < strlen(alphabet); ++i) out << bg->getV()[0][i] << (i + 1 != strlen(alphabet) ? ", " : "");
+  out << "]," << std::endl;
+  out << "\t\"alphabet_length\" : " << 4 << "," << std::endl;
+  out << "\t\"patterns\" : [" << std::endl;
+  for (size_t n = 0; n < pats.size(); ++n) {
+    IUPACPattern* p = pats[n];
+    out << "\t\t{" << std::endl;
+    out << "\t\t\t\"iupac_motif\" : \"" << p->get_pattern_string() << "\"," << std::endl;
+    out << "\t\t\t\"pattern_length\" : " << p->get_pattern_length() << "," << std::endl;
+    out << "\t\t\t\"sites\" : " << p->get_sites() << "," << std::endl;
+    out << "\t\t\t\"log(Pval)\" : " << p->getLogPval() << "," << std::endl;
+    out << "\t\t\t\"bg_prob\" : " << p->get_bg_p() << "," << std::endl;
+    out << "\t\t\t\"opt_bg_order\" : " << p->get_optimization_bg_model_order() << "," << std::endl;
+    out << "\t\t\t\"pwm\" : [" << std::endl;
+    float** pwm = p->get_pwm();
+    no_zero_pwm(pwm, (unsigned)p->get_pattern_length(), PRECISION);
+    for (size_t w = 0; w < p->get_pattern_length(); ++w) {
+      out << "\t\t\t\t\t[";
+      for (size_t a = 0; a < 4; ++a) out << std::fixed << std::setprecision(PRECISION) << pwm[w][a] << (a != 3 ? ", " : "]");
+      if (w + 1 != p->get_pattern_length()) out << ", ";
+      out << std::endl;
+    }
+    out << "\t\t\t\t]" << std::endl;
+    out << "\t\t}" << (n + 1 != pats.size() ? "," : "") << std::endl;
+  }
+  out << "\t]" << std::endl;
+  out << "}" << std::endl;
+}

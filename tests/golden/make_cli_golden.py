@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""End-to-end fixtures from the reference CLI (oracle/_ref/peng_motif_ref, built from /root/reference by
+oracle/Makefile): MEME, JSON and stdout for BASELINE configs 1 and 2 and a few flag variants.
+Run in the build container only:  make -C oracle ref && python tests/golden/make_cli_golden.py"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "peng_motif_ref")
+
+CASES = {
+    # name: (fasta, extra args)
+    "cli_mafk100_w8": ("MafK_100seqs.fasta", ["-w", "8"]),                          # BASELINE config 1
+    "cli_mafk100_w6_plus_noem": ("MafK_100seqs.fasta", ["-w", "6", "--strand", "PLUS", "--no-em"]),
+    "cli_mafk100_w8_logpval_nomerge": ("MafK_100seqs.fasta", ["-w", "8", "--optimization_score", "LOGPVAL", "--no-merging", "-t", "5"]),
+    "cli_mafk_w10": ("MafK.fasta", ["-w", "10"]),                                    # BASELINE config 2
+    "cli_mafk_w10_plus": ("MafK.fasta", ["-w", "10", "--strand", "PLUS"]),
+    "cli_torture_w6": ("torture.fa", ["-w", "6", "-t", "3", "--count-threshold", "2"]),
+}
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("build the reference first: make -C oracle ref")
+    out = os.path.join(HERE, "cli")
+    os.makedirs(out, exist_ok=True)
+    for name, (fasta, extra) in CASES.items():
+        meme = os.path.join(out, name + ".meme")
+        js = os.path.join(out, name + ".json")
+        cmd = [REF, os.path.join(HERE, fasta)] + extra + ["-o", meme, "-j", js]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        open(os.path.join(out, name + ".stdout"), "wb").write(r.stdout)
+        open(os.path.join(out, name + ".args"), "w").write(" ".join([fasta] + extra) + "\n")
+        print(name, "rc", r.returncode, "motifs", open(meme).read().count("MOTIF"))
+
+
+if __name__ == "__main__":
+    main()
