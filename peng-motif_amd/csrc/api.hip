@@ -91,6 +91,7 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_em_partials) (void)hipFree(ctx->d_em_partials);
   if (ctx->d_misc) (void)hipFree(ctx->d_misc);
   if (ctx->d_keys) (void)hipFree(ctx->d_keys);
+  if (ctx->d_iupac_big) (void)hipFree(ctx->d_iupac_big);
   if (ctx->d_bg_partials) (void)hipFree(ctx->d_bg_partials);
   if (ctx->d_count_aux) (void)hipFree(ctx->d_count_aux);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -1,18 +1,19 @@
-// iupac.hip -- K4: IUPAC degenerate-pattern aggregation, one thread per pattern (gfx950).
+// iupac.hip -- K4: IUPAC degenerate-pattern aggregation (gfx950).
 //
 // Replaces IUPACPattern::basepatterns_from_iupac_{single,double}_stranded + the summation loop of
 // aggregate_attributes_from_basepatterns / count_combined_occurences
-// (src/iupac_pattern.cpp:331-473,806-833).  No id list is materialised and nothing is sorted:
+// (src/iupac_pattern.cpp:331-473,806-833).
 //
 //  * PLUS: the reference's LIFO stack emits an odometer in which the LAST degenerate position moves
-//    fastest and every position runs rep[0], rep[n-1], ..., rep[1]; the thread walks that odometer
-//    and adds count / background / expected in exactly that order (the float32 sums are
-//    order-sensitive).
+//    fastest and every position runs rep[0], rep[n-1], ..., rep[1]; count / background / expected are
+//    added in exactly that order (the float32 sums are order-sensitive).
 //  * BOTH: the reference canonicalises (min(id, rc)), sorts ascending and skips adjacent
-//    duplicates, i.e. it sums over the DISTINCT canonical ids in ascending order.  That set is
-//    { c in E(P) u E(rc P) : c <= rc(c) }, so the thread merges two ascending odometers (P and its
-//    reverse-complement pattern), keeps canonical members and drops the duplicate when both
-//    streams carry the same id.
+//    duplicates, i.e. it sums over the DISTINCT canonical ids in ascending order.
+//
+// Only the float32 fold is inherently serial.  Everything else is parallel: a workgroup per small
+// pattern (ids sorted in LDS), a grid-wide bitmap / compaction / gather pipeline per large pattern, and
+// a v_readlane chain that folds 64 gathered values at a time in the reference's order.
+// (Round 1 started with one thread per pattern: 3.2 s of hill-climb on MafK W=10; now 0.1 s.)
 //
 // The three sums come back to the host; z-score and log-p (O(1) scalar double math per pattern,
 // :446-470) are finished in launch_iupac with the same libm the reference links.
@@ -39,108 +40,239 @@ struct RawSums {
 
 constexpr int MAXW = PENGK_MAX_W;
 
-// ascending odometer over the expansion of one IUPAC pattern (position W-1 most significant)
-struct AscStream {
-  int letter[MAXW];
-  int idx[MAXW];
-  uint32_t cur;
-  bool done;
-  int W;
-  __device__ void init(const int* letters, int W_) {
-    W = W_;
-    cur = 0;
-    done = false;
-    for (int p = 0; p < W; ++p) {
-      letter[p] = letters[p];
-      idx[p] = 0;
-      cur |= (uint32_t)c_rep[letters[p]][0] << (2 * p);
-    }
-  }
-  __device__ void step() {
-    for (int p = 0; p < W; ++p) {
-      const int L = letter[p];
-      const int n = c_rep_n[L];
-      if (idx[p] + 1 < n) {
-        cur += (uint32_t)(c_rep[L][idx[p] + 1] - c_rep[L][idx[p]]) << (2 * p);
-        ++idx[p];
-        return;
-      }
-      cur -= (uint32_t)(c_rep[L][idx[p]] - c_rep[L][0]) << (2 * p);
-      idx[p] = 0;
-    }
-    done = true;
-  }
-  // move to the first canonical member at or after the current one
-  __device__ void settle() {
-    while (!done && cur > revcomp32(cur, W)) step();
-  }
-};
+// ---------------------------------------------------------------------------------------------
+// K4 v2: one 256-thread workgroup per pattern.  The float32 sums must be formed in the reference's
+// order, but nothing else has to be serial: all threads generate / sort the ids and gather the three
+// table values; then one wave folds 64 values at a time with a v_readlane chain (2 dependent adds per
+// element instead of three dependent HBM/L2 gathers per element in the thread-per-pattern kernel).
+//   PLUS: element k of the LIFO odometer is unranked directly (letter sets have 1, 2 or 4 members,
+//         so the mixed radix is bit slicing).
+//   BOTH: min(id, rc(id)) of all members is sorted in LDS (bitonic), adjacent duplicates contribute 0.
+// Patterns with more than IUPAC_LDS_MAX members fall back to the thread-per-pattern kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int IUPAC_LDS_MAX = 8192;
 
-__global__ __launch_bounds__(64) void iupac_kernel(int W, int both, const unsigned long long* __restrict__ ids, int n,
-                                                   const uint32_t* __restrict__ counts, const float* __restrict__ bgp,
-                                                   const float* __restrict__ expected, RawSums* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int letters[MAXW];
-  {
-    unsigned long long t = ids[i];
+__device__ __forceinline__ float chain_add(float acc, float v) {
+  // acc + v[0] + v[1] + ... + v[63], strictly left to right (wave-uniform result)
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void iupac_block_kernel(int W, int both, const unsigned long long* __restrict__ ids, int n_pat,
+                                                          const uint32_t* __restrict__ counts,
+                                                          const float* __restrict__ bgp, const float* __restrict__ expected,
+                                                          RawSums* __restrict__ out) {
+  __shared__ uint32_t s_ids[IUPAC_LDS_MAX];
+  __shared__ float s_bg[256], s_ex[256];
+  __shared__ unsigned long long s_cnt;
+  __shared__ int s_letters[MAXW];
+  const int pat = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    unsigned long long t = ids[pat];
     for (int p = 0; p < W; ++p) {
-      letters[p] = (int)(t % 11ull);
+      s_letters[p] = (int)(t % 11ull);
       t /= 11ull;
     }
+    s_cnt = 0;
   }
-  unsigned long long sum_c = 0;
+  __syncthreads();
+  int lg[MAXW];  // log2 of the letter-set sizes
+  int lgn = 0;
+  for (int p = 0; p < W; ++p) {
+    const int sz = c_rep_n[s_letters[p]];
+    lg[p] = sz == 1 ? 0 : (sz == 2 ? 1 : 2);
+    lgn += lg[p];
+  }
+  const uint32_t n = 1u << lgn;
+  if (n > (uint32_t)IUPAC_LDS_MAX) return;  // block-uniform: launch_iupac runs the list pipeline for this one
+  // member k in the reference's emission order (last degenerate position fastest; rep[0], rep[n-1], ..., rep[1])
+  auto member = [&](uint32_t k) -> uint32_t {
+    uint32_t x = 0;
+    for (int p = W - 1; p >= 0; --p) {
+      const int sz = 1 << lg[p];
+      const int d = (int)(k & (uint32_t)(sz - 1));
+      k >>= lg[p];
+      const int j = d == 0 ? 0 : sz - d;
+      x |= (uint32_t)c_rep[s_letters[p]][j] << (2 * p);
+    }
+    return x;
+  };
+  uint32_t npad = n;
+  if (both) {
+    for (uint32_t k = tid; k < n; k += 256) {
+      const uint32_t x = member(k);
+      const uint32_t r = revcomp32(x, W);
+      s_ids[k] = x < r ? x : r;
+    }
+    __syncthreads();
+    // bitonic sort, ascending (n is a power of two)
+    for (uint32_t size = 2; size <= n; size <<= 1)
+      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+        for (uint32_t i = tid; i < (n >> 1); i += 256) {
+          const uint32_t lo = 2 * i - (i & (stride - 1));  // index with bit `stride` clear
+          const uint32_t hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          const uint32_t a = s_ids[lo], b = s_ids[hi];
+          if ((a > b) == up) {
+            s_ids[lo] = b;
+            s_ids[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+  }
+  (void)npad;
   float sum_bg = 0.0f, sum_e = 0.0f;
-  if (!both) {
-    int stepv[MAXW];
-    unsigned long long total = 1;
-    for (int p = 0; p < W; ++p) {
-      stepv[p] = 0;
-      total *= (unsigned long long)c_rep_n[letters[p]];
-    }
-    for (unsigned long long k = 0; k < total; ++k) {
-      uint32_t x = 0;
-      for (int p = 0; p < W; ++p) {
-        const int cnt = c_rep_n[letters[p]];
-        const int j = stepv[p] == 0 ? 0 : cnt - stepv[p];
-        x |= (uint32_t)c_rep[letters[p]][j] << (2 * p);
+  unsigned long long my_cnt = 0;
+  for (uint32_t base = 0; base < n; base += 256) {
+    const uint32_t k = base + tid;
+    float vb = 0.0f, ve = 0.0f;
+    if (k < n) {
+      uint32_t x;
+      bool take = true;
+      if (both) {
+        x = s_ids[k];
+        take = (k == 0) || (s_ids[k - 1] != x);
+      } else {
+        x = member(k);
       }
-      sum_bg += bgp[x];
-      sum_c += counts[x];
-      sum_e += expected[x];
-      for (int p = W - 1; p >= 0; --p) {
-        if (++stepv[p] < c_rep_n[letters[p]]) break;
-        stepv[p] = 0;
+      if (take) {
+        vb = bgp[x];
+        ve = expected[x];
+        my_cnt += counts[x];
       }
     }
-  } else {
-    int rcl[MAXW];
-    for (int p = 0; p < W; ++p) rcl[p] = c_comp[letters[W - 1 - p]];
-    AscStream a, b;
-    a.init(letters, W);
-    b.init(rcl, W);
-    a.settle();
-    b.settle();
-    while (!a.done || !b.done) {
-      const uint32_t xa = a.done ? 0xFFFFFFFFu : a.cur;
-      const uint32_t xb = b.done ? 0xFFFFFFFFu : b.cur;
-      const uint32_t x = xa < xb ? xa : xb;
-      sum_bg += bgp[x];
-      sum_c += counts[x];
-      sum_e += expected[x];
-      if (xa == x) {
-        a.step();
-        a.settle();
+    s_bg[tid] = vb;
+    s_ex[tid] = ve;
+    __syncthreads();
+    if (tid < 64) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (base + 64u * q < n) {  // wave-uniform
+          sum_bg = chain_add(sum_bg, s_bg[q * 64 + tid]);
+          sum_e = chain_add(sum_e, s_ex[q * 64 + tid]);
+        }
       }
-      if (xb == x) {
-        b.step();
-        b.settle();
-      }
+    }
+    __syncthreads();
+  }
+  if (my_cnt) atomicAdd(&s_cnt, my_cnt);
+  __syncthreads();
+  if (tid == 0) {
+    out[pat].sites = s_cnt;
+    out[pat].bg_p = sum_bg;
+    out[pat].expected = sum_e;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// K4 for patterns too large for one workgroup's LDS (thousands to 4^W members; N-rich mutants of the
+// hill-climb).  Everything except the float32 fold is data-parallel:
+//   BOTH: mark min(id, rc) of every member in a 4^W-bit map (the map IS the sorted, de-duplicated
+//         list), compact it to an ascending id array with a popcount scan;
+//   PLUS: no list -- member k of the emission order is unranked on the fly;
+//   then gather the table values in list order (grid-wide) and fold them 64 at a time in one wave.
+// ---------------------------------------------------------------------------------------------
+struct PatternSpec {
+  unsigned long long letters4;  // 4 bits per position
+  int W;
+  int lgn;
+};
+
+__device__ __forceinline__ uint32_t spec_member(const PatternSpec& ps, uint32_t k) {
+  uint32_t x = 0;
+  for (int p = ps.W - 1; p >= 0; --p) {
+    const int L = (int)((ps.letters4 >> (4 * p)) & 15ull);
+    const int sz = c_rep_n[L];
+    const int lg = sz == 1 ? 0 : (sz == 2 ? 1 : 2);
+    const int d = (int)(k & (uint32_t)(sz - 1));
+    k >>= lg;
+    x |= (uint32_t)c_rep[L][d == 0 ? 0 : sz - d] << (2 * p);
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(256) void iupac_mark_kernel(PatternSpec ps, uint32_t* __restrict__ bitmap) {
+  const uint32_t n = 1u << ps.lgn;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const uint32_t x = spec_member(ps, k);
+    const uint32_t r = revcomp32(x, ps.W);
+    const uint32_t c = x < r ? x : r;
+    atomicOr(&bitmap[c >> 5], 1u << (c & 31u));
+  }
+}
+
+// one workgroup: ascending ids of the set bits -> out_ids, their number -> *out_m
+__global__ __launch_bounds__(1024) void iupac_compact_kernel(const uint32_t* __restrict__ bitmap, uint32_t n_words,
+                                                             uint32_t* __restrict__ out_ids, uint32_t* __restrict__ out_m) {
+  __shared__ uint32_t s_scan[1024];
+  const uint32_t per = (n_words + 1023u) / 1024u;
+  const uint32_t w0 = threadIdx.x * per, w1 = min(n_words, w0 + per);
+  uint32_t mine = 0;
+  for (uint32_t w = w0; w < w1; ++w) mine += __popc(bitmap[w]);
+  s_scan[threadIdx.x] = mine;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const uint32_t v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
+    __syncthreads();
+    s_scan[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t at = s_scan[threadIdx.x] - mine;
+  for (uint32_t w = w0; w < w1; ++w) {
+    uint32_t bits = bitmap[w];
+    while (bits) {
+      const uint32_t b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      out_ids[at++] = (w << 5) | b;
     }
   }
-  out[i].sites = sum_c;
-  out[i].bg_p = sum_bg;
-  out[i].expected = sum_e;
+  if (threadIdx.x == 1023) *out_m = s_scan[1023];
+}
+
+// values in list order; ids == nullptr: list = emission order of `ps` (PLUS), m = 2^lgn
+__global__ __launch_bounds__(256) void iupac_gather_kernel(PatternSpec ps, const uint32_t* __restrict__ ids,
+                                                           const uint32_t* __restrict__ m_ptr,
+                                                           const uint32_t* __restrict__ counts, const float* __restrict__ bgp,
+                                                           const float* __restrict__ expected, float* __restrict__ vb,
+                                                           float* __restrict__ ve, unsigned long long* __restrict__ cnt_out) {
+  const uint32_t m = ids ? *m_ptr : (1u << ps.lgn);
+  unsigned long long mine = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const uint32_t x = ids ? ids[i] : spec_member(ps, i);
+    vb[i] = bgp[x];
+    ve[i] = expected[x];
+    mine += counts[x];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(cnt_out, mine);
+}
+
+// one wave: strictly sequential float32 sums of vb[0..m) and ve[0..m)
+__global__ __launch_bounds__(64) void iupac_fold_kernel(const float* __restrict__ vb, const float* __restrict__ ve,
+                                                        const uint32_t* __restrict__ m_ptr, uint32_t m_fixed,
+                                                        const unsigned long long* __restrict__ cnt, RawSums* __restrict__ out) {
+  const uint32_t m = m_ptr ? *m_ptr : m_fixed;
+  const uint32_t lane = threadIdx.x;
+  float sb = 0.0f, se = 0.0f;
+  float nb = lane < m ? vb[lane] : 0.0f, ne = lane < m ? ve[lane] : 0.0f;
+  for (uint32_t base = 0; base < m; base += 64) {
+    const float cb = nb, ce = ne;
+    const uint32_t nx = base + 64 + lane;  // prefetch the next 64 while this chain runs
+    nb = nx < m ? vb[nx] : 0.0f;
+    ne = nx < m ? ve[nx] : 0.0f;
+    sb = chain_add(sb, cb);
+    se = chain_add(se, ce);
+  }
+  if (lane == 0) {
+    out->sites = *cnt;
+    out->bg_p = sb;
+    out->expected = se;
+  }
 }
 
 float log_bonferroni(int letter) {  // src/iupac_pattern.cpp:199-210
@@ -157,14 +289,57 @@ int launch_iupac(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids, int64_t
   const size_t id_bytes = (size_t)n * sizeof(uint64_t);
   const size_t out_bytes = (size_t)n * sizeof(RawSums);
   const size_t id_pad = (id_bytes + 255) & ~(size_t)255;
-  int rc = ensure_scratch(ctx, &ctx->d_misc, &ctx->misc_bytes, id_pad + out_bytes);
+  const size_t out_pad = (out_bytes + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, &ctx->d_misc, &ctx->misc_bytes, id_pad + out_pad);
   if (rc) return rc;
   unsigned long long* d_ids = (unsigned long long*)ctx->d_misc;
   RawSums* d_out = (RawSums*)((char*)ctx->d_misc + id_pad);
   PENGK_HIP(hipMemcpyAsync(d_ids, h_ids, id_bytes, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(iupac_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, W, both, d_ids, (int)n, d_counts,
-                     d_bgp, d_expected, d_out);
+  // small patterns (<= IUPAC_LDS_MAX members): one workgroup each, all in one launch
+  hipLaunchKernelGGL(iupac_block_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, W, both, d_ids, (int)n, d_counts, d_bgp,
+                     d_expected, d_out);
   PENGK_HIP(hipGetLastError());
+  // large patterns: the data-parallel list pipeline, one pattern after the other
+  static const int rep_n[11] = {1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 4};
+  for (int64_t i = 0; i < n; ++i) {
+    PatternSpec ps{0ull, W, 0};
+    uint64_t t = h_ids[i];
+    for (int p = 0; p < W; ++p) {
+      const int L = (int)(t % 11);
+      t /= 11;
+      ps.letters4 |= (unsigned long long)L << (4 * p);
+      ps.lgn += rep_n[L] == 1 ? 0 : (rep_n[L] == 2 ? 1 : 2);
+    }
+    if ((1ull << ps.lgn) <= (unsigned long long)IUPAC_LDS_MAX) continue;
+    const uint32_t nmem = 1u << ps.lgn;
+    const uint32_t n_words = 1u << (2 * W - 5);
+    // scratch: bitmap | m | cnt | ids | vb | ve
+    const size_t bm_bytes = (size_t)n_words * 4, list_bytes = (size_t)nmem * 4;
+    rc = ensure_scratch(ctx, &ctx->d_iupac_big, &ctx->iupac_big_bytes, bm_bytes + 256 + 3 * list_bytes);
+    if (rc) return rc;
+    uint32_t* bitmap = (uint32_t*)ctx->d_iupac_big;
+    uint32_t* d_m = (uint32_t*)((char*)ctx->d_iupac_big + bm_bytes);
+    unsigned long long* d_cnt = (unsigned long long*)((char*)d_m + 64);
+    uint32_t* lst = (uint32_t*)((char*)ctx->d_iupac_big + bm_bytes + 256);
+    float* vb = (float*)(lst + nmem);
+    float* ve = vb + nmem;
+    PENGK_HIP(hipMemsetAsync(d_m, 0, 256, ctx->stream));
+    const unsigned gblocks = nmem / 256 < 2048u ? nmem / 256 : 2048u;
+    if (both) {
+      PENGK_HIP(hipMemsetAsync(bitmap, 0, bm_bytes, ctx->stream));
+      hipLaunchKernelGGL(iupac_mark_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, ps, bitmap);
+      hipLaunchKernelGGL(iupac_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, bitmap, n_words, lst, d_m);
+      hipLaunchKernelGGL(iupac_gather_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, ps, lst, d_m, d_counts, d_bgp, d_expected, vb,
+                         ve, d_cnt);
+      hipLaunchKernelGGL(iupac_fold_kernel, dim3(1), dim3(64), 0, ctx->stream, vb, ve, d_m, 0u, d_cnt, d_out + i);
+    } else {
+      hipLaunchKernelGGL(iupac_gather_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, ps, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, d_counts, d_bgp, d_expected, vb, ve, d_cnt);
+      hipLaunchKernelGGL(iupac_fold_kernel, dim3(1), dim3(64), 0, ctx->stream, vb, ve, (const uint32_t*)nullptr, nmem, d_cnt,
+                         d_out + i);
+    }
+    PENGK_HIP(hipGetLastError());
+  }
   RawSums* raw = new (std::nothrow) RawSums[(size_t)n];
   if (!raw) return fail(PENGK_ERR_NOMEM, "pengk_iupac_aggregate: out of host memory");
   hipError_t e = hipMemcpyAsync(raw, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);

@@ -28,6 +28,8 @@ struct pengk_ctx {
   size_t misc_bytes = 0;
   void* d_bg_partials = nullptr;  // fused K1b: per-block bins
   size_t bg_partials_bytes = 0;
+  void* d_iupac_big = nullptr;  // K4 large patterns: bitmap | list | values
+  size_t iupac_big_bytes = 0;
   void* d_keys = nullptr;  // partitioned count: bucket regions of 16-bit keys
   size_t keys_bytes = 0;
   void* d_count_aux = nullptr;  // partitioned count: cursors + bucket-major table

@@ -1,6 +1,8 @@
 // peng_motif -- command-line entry of the MI355X mirror: same flags, stdout trace, MEME / JSON output
 // and exit codes as the reference's src/main.cpp; the hot loops run on the GPU through libpengk.
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <iostream>
 
 #include "Global.h"
@@ -8,14 +10,36 @@
 #include "iupac_pattern.h"
 #include "peng.h"
 
+namespace {
+// PENGK_TIMING=1: wall-clock phase report on stderr (stdout stays the reference's trace)
+struct PhaseClock {
+  using clk = std::chrono::steady_clock;
+  bool on = std::getenv("PENGK_TIMING") != nullptr;
+  clk::time_point t0 = clk::now(), last = t0;
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = clk::now();
+    std::cerr << "[timing] " << what << ": " << std::chrono::duration<double>(now - last).count() << " s" << std::endl;
+    last = now;
+  }
+  void total() {
+    if (on) std::cerr << "[timing] total: " << std::chrono::duration<double>(clk::now() - t0).count() << " s" << std::endl;
+  }
+};
+}  // namespace
+
 int main(int nargs, char** args) {
+  PhaseClock clock;
   Global::init(nargs, args);
+  clock.lap("read FASTA");
   pengk_host::context();  // fail early (exit 1) when no gfx950 device is present: there is no CPU path
+  clock.lap("device context");
 
   const int bg_model_order = std::max(Global::bgModelOrder, Global::maxOptBgModelOrder);
   BackgroundModel* bgModel =
       new BackgroundModel(*Global::backgroundSequenceSet, bg_model_order, Global::bgModelAlpha, Global::interpolateBG);
 
+  clock.lap("background model");
   Peng peng(Global::strand, Global::bgModelOrder, Global::maxOptBgModelOrder, Global::inputSequenceSet, bgModel);
 
   PengParameters params;
@@ -39,6 +63,7 @@ int main(int nargs, char** args) {
 
   std::vector<IUPACPattern*> result;
   peng.process(params, result);
+  clock.lap("process (count, sweep, hill-climb, PWMs, EM, merging)");
   peng.filter_redundancy(Global::mergeBitfactorThreshold, result);
   if (Global::outputFilename) peng.printShortMeme(result, Global::outputFilename, bgModel);
   if (Global::jsonFilename) peng.printJson(result, Global::jsonFilename, VERSION_NUMBER, bgModel);
@@ -47,5 +72,7 @@ int main(int nargs, char** args) {
   delete bgModel;
   Global::destruct();
   pengk_host::shutdown();
+  clock.lap("output + cleanup");
+  clock.total();
   return 0;
 }
