@@ -28,14 +28,8 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
   const size_t NP = number_patterns;
 
   // ---- sequences -> 2-bit stream + scan items (host packer resolves the N / skip scan rule) ----------
-  std::vector<uint8_t> codes;
-  std::vector<int64_t> offs(1, 0);
-  for (Sequence* q : sequence_set->sequences()) {
-    codes.insert(codes.end(), q->getSequence(), q->getSequence() + q->getL());
-    offs.push_back((int64_t)codes.size());
-  }
   pengk_packed pk;
-  check(pengk_pack(codes.data(), offs.data(), (int64_t)offs.size() - 1, W, 0, &pk), "pengk_pack");
+  check(pengk_pack(sequence_set->codes(), sequence_set->offsets(), (int64_t)sequence_set->getN(), W, 0, &pk), "pengk_pack");
   pengk_host::DeviceBuffer<uint64_t> d_words(pk.n_words), d_items(pk.n_items + 1), d_ltot(1);
   d_words.upload(pk.words, pk.n_words);
   if (pk.n_items) d_items.upload(pk.items, pk.n_items);

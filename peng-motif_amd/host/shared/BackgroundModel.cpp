@@ -4,7 +4,9 @@
 #include "BackgroundModel.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
+#include <thread>
 
 BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vector<float> alpha, bool interpolate,
                                  std::vector<std::vector<int>>, std::vector<int>) {
@@ -24,19 +26,75 @@ BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vecto
     n_[k] = new long long[1 << (2 * (k + 1))]();
     v_[k] = new float[1 << (2 * (k + 1))]();
   }
-  for (Sequence* s : sequenceSet.sequences()) {
-    const uint8_t* seq = s->getSequence();
-    const int L = s->getL();
-    unsigned digits = 0, invalid = 0;  // rolling 9-base window
-    for (int i = 0; i < L; ++i) {
-      const unsigned c = seq[i];
-      digits = ((digits << 2) | (c ? c - 1u : 0u)) & 0x3FFFFu;
-      invalid = ((invalid << 1) | (c == 0)) & 0x1FFu;
-      for (int k = 0; k <= K_ && k <= i; ++k) {
-        const unsigned y = digits & ((1u << (2 * (k + 1))) - 1u);
-        if (invalid == 0 || y == 0) ++n_[k][y];
+  // count over the contiguous code buffer, split over host threads by sequence ranges
+  const uint8_t* codes = sequenceSet.codes();
+  const int64_t* offs = sequenceSet.offsets();
+  const size_t N = sequenceSet.getN();
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 32) nt = 32;
+  if (N == 0 || (size_t)offs[N] < (1u << 22)) nt = 1;
+  std::vector<std::vector<long long>> part(nt, std::vector<long long>(168, 0));  // [0,84) fast path, [84,168) exact path
+  auto work = [&](unsigned t) {
+    long long* c[3] = {part[t].data(), part[t].data() + 4, part[t].data() + 20};
+    for (size_t s = N * t / nt; s < N * (t + 1) / nt; ++s) {
+      const uint8_t* seq = codes + offs[s];
+      const int64_t L = offs[s + 1] - offs[s];
+      if (!std::memchr(seq, 0, (size_t)L)) {
+        // no invalid base: one 3-mer bin per base; 1- and 2-mer counts follow as marginals below, with the
+        // first base / first 2-mer of the sequence added (they end no 3-mer)
+        unsigned y = 0;
+        if (L >= 1) {
+          y = seq[0] - 1u;
+          ++c[0][y];
+        }
+        if (L >= 2) {
+          y = (y << 2) | (seq[1] - 1u);
+          ++c[1][y];
+        }
+        long long* c3 = c[2];
+        for (int64_t i = 2; i < L; ++i) {
+          y = ((y << 2) | (seq[i] - 1u)) & 63u;
+          ++c3[y];
+        }
+        continue;
+      }
+      // exact rule with invalid bases: all orders counted directly; marked so the marginals skip them
+      long long* d[3] = {part[t].data() + 84, part[t].data() + 88, part[t].data() + 104};
+      unsigned digits = 0, invalid = 0;  // rolling 9-base window
+      for (int64_t i = 0; i < L; ++i) {
+        const unsigned b = seq[i];
+        digits = ((digits << 2) | (b ? b - 1u : 0u)) & 0x3FFFFu;
+        invalid = ((invalid << 1) | (b == 0)) & 0x1FFu;
+        for (int k = 0; k <= 2 && k <= i; ++k) {
+          const unsigned y = digits & ((1u << (2 * (k + 1))) - 1u);
+          if (invalid == 0 || y == 0) ++d[k][y];
+        }
       }
     }
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+  }
+  for (unsigned t = 0; t < nt; ++t) {
+    const long long* f = part[t].data();
+    const long long* e = part[t].data() + 84;
+    // fast path: f[0..4) first bases, f[4..20) first 2-mers, f[20..84) 3-mers ending at i >= 2
+    long long n2[16], n1[4];
+    for (int ab = 0; ab < 16; ++ab) {
+      n2[ab] = f[4 + ab];
+      for (int x = 0; x < 4; ++x) n2[ab] += f[20 + x * 16 + ab];
+    }
+    for (int a = 0; a < 4; ++a) {
+      n1[a] = f[a];
+      for (int x = 0; x < 4; ++x) n1[a] += n2[x * 4 + a];
+    }
+    for (int y = 0; y < 4; ++y) n_[0][y] += n1[y] + e[y];
+    for (int y = 0; y < 16; ++y) n_[1][y] += n2[y] + e[4 + y];
+    for (int y = 0; y < 64; ++y) n_[2][y] += f[20 + y] + e[20 + y];
   }
   calculateV();
 }

@@ -19,7 +19,18 @@ Sequence::Sequence(uint8_t* sequence, int L, std::string header, std::vector<int
   }
 }
 
-Sequence::~Sequence() { std::free(codes_); }
+Sequence* Sequence::view(uint8_t* codes, int L, std::string header) {
+  Sequence* s = new Sequence();
+  s->codes_ = codes;
+  s->L_ = L;
+  s->owns_ = false;
+  s->header_ = std::move(header);
+  return s;
+}
+
+Sequence::~Sequence() {
+  if (owns_) std::free(codes_);
+}
 
 std::unique_ptr<uint8_t[]> Sequence::createReverseComplement() {
   std::unique_ptr<uint8_t[]> rc{new uint8_t[L_ ? L_ : 1]};

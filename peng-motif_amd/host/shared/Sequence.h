@@ -1,6 +1,8 @@
 // Sequence -- one FASTA record as byte codes (interface subset of src/shared/Sequence.h).
 // The reference additionally precomputes a 9-mer int per base (Sequence.cpp:28-33) that only its
 // BackgroundModel reads; here BackgroundModel derives the same counters directly from the codes.
+// A Sequence either owns its codes (public constructor, as in the reference) or is a view into the
+// contiguous code buffer of its SequenceSet (how the FASTA reader creates them).
 #ifndef PENGK_HOST_SEQUENCE_H_
 #define PENGK_HOST_SEQUENCE_H_
 
@@ -15,6 +17,7 @@
 class Sequence {
  public:
   Sequence(uint8_t* sequence, int L, std::string header, std::vector<int> Y, bool singleStrand = false);
+  static Sequence* view(uint8_t* codes, int L, std::string header);  // non-owning
   ~Sequence();
   uint8_t* getSequence() { return codes_; }
   int getL() { return L_; }
@@ -22,8 +25,10 @@ class Sequence {
   std::unique_ptr<uint8_t[]> createReverseComplement();
 
  private:
-  uint8_t* codes_;
-  int L_;
+  Sequence() = default;
+  uint8_t* codes_ = nullptr;
+  int L_ = 0;
+  bool owns_ = true;
   std::string header_;
 };
 

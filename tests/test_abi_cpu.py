@@ -131,3 +131,25 @@ def test_synth_sizes():
     assert pk.lib().pengk_synth_sizes(10, 300, 10, 64, C.byref(nw), C.byref(ni)) == 0
     assert ni.value == 10 * 5
     assert pk.lib().pengk_synth_sizes(10, 8, 10, 64, C.byref(nw), C.byref(ni)) == pk.ERR_ARG
+
+
+def test_packer_is_thread_count_invariant(monkeypatch):
+    """the two-pass threaded packer writes the same stream, items and counters for any number of host threads"""
+    rng = np.random.default_rng(9)
+    lens = rng.integers(1, 400, size=3000)
+    codes = rng.integers(1, 5, size=int(lens.sum())).astype(np.uint8)
+    codes[rng.integers(0, len(codes), size=400)] = 0  # invalid bases split runs
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ref = None
+    for nt in (1, 2, 7, 16):
+        monkeypatch.setenv("PENGK_PACK_THREADS", str(nt))
+        p = pk.Packed(codes, offs, 8, 64)
+        cur = (p.words.tobytes(), p.items.tobytes(), p.bg_counts.tobytes(), p.n_windows, p.max_bin_bound, p.all_whole, p.max_len)
+        if ref is None:
+            ref = cur
+            want, ltot = po.count(codes, offs, 8, False)
+            assert p.n_windows == ltot
+            assert np.array_equal(greedy_count(unpack_windows(p, False), 8, 4 ** 8), want)
+            assert np.array_equal(p.bg_counts, po.bg_counts(codes, offs, 2))
+        else:
+            assert cur == ref, nt
