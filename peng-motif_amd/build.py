@@ -25,6 +25,9 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+EXTRA = os.environ.get("PENGK_EXTRA_FLAGS", "").split()  # experiments, e.g. -DPENGK_RING_CAP=64
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -42,7 +45,7 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     for s in SOURCES:
         o = os.path.join(objdir, s + ".o")
-        cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc()] + FLAGS + EXTRA + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(CSRC, s), "-o", o]
         if s.endswith(".cpp"):
             cmd.insert(1, "-xhip")
         if verbose:

@@ -17,6 +17,10 @@
 // defer list and redone by count_fixup_kernel, which searches backwards for a certified start.
 #include "pengk_internal.h"
 
+#ifndef PENGK_RING_CAP
+#define PENGK_RING_CAP 128
+#endif
+
 namespace pengk {
 
 namespace {
@@ -54,7 +58,7 @@ template <int W, bool BG>
 struct BgCount {
   uint32_t wave;
   __device__ __forceinline__ void kmer3(uint32_t id, bool on) const {
-    if (BG && on) atomicAdd(&bg_lds().bins[wave][id >> (2 * W - 6)], 1u);
+    if (BG) atomicAdd(&bg_lds().bins[wave][on ? (id >> (2 * W - 6)) : 95u], 1u);  // bin 95 is a sink: no exec-mask dance
   }
   // base at run position sp (static) of a non-continuing item, id already rolled
   __device__ __forceinline__ void head(uint32_t id, int sp, bool on) const {
@@ -187,9 +191,13 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
         id = (id >> 2) | (c << G::TOP);
         rc = ((rc << 2) & G::MASK) | (c ^ 3u);
         const uint32_t can = BOTH ? min(id, rc) : id;
-        bool match = false;
+        // "can equals one of the last W-1 counted ids" as min over xors == 0: VALU only.  (The obvious
+        // v_cmp_eq chain costs 8 s_or_b64 per window and the kernel was bound by the CU's single scalar
+        // ALU: 42 SALU instructions per window, profiles/r01_v3_pmc_sq.txt.)
+        uint32_t diff = can ^ ring[(u - 1) & 15];
 #pragma unroll
-        for (int d = 1; d <= W - 1; ++d) match |= (can == ring[(u - d) & 15]);
+        for (int d = 2; d <= W - 1; ++d) diff = min(diff, can ^ ring[(u - d) & 15]);
+        const bool match = diff == 0u;
         ring[u] = match ? INVALID_ID : can;
         bgc.kmer3(id, t0 + (uint32_t)u < nw_all);
         emit(can, !match && t0 + (uint32_t)u < nw);
@@ -246,7 +254,8 @@ __global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__
 // Skewed inputs cannot break it: a slice that runs full makes further groups of that (wave, bucket)
 // fall back to direct atomics on the final table (graceful degradation to variant 1).
 // ---------------------------------------------------------------------------------------------
-constexpr int RING_CAP = 128;       // u16 entries per (wave, bucket) ring
+constexpr int RING_CAP = PENGK_RING_CAP;  // u16 entries per (wave, bucket) ring
+constexpr int GROUP = RING_CAP / 2;        // entries written per flush (one 128-byte line at RING_CAP = 128)
 constexpr uint32_t KEY_INVALID = 0xFFFFu;
 constexpr int PAYLOAD_BITS = 15;
 
@@ -270,8 +279,8 @@ struct KeySplit {
 template <int NBITS>
 struct ScatterShared {
   static constexpr int NB = 1 << NBITS;
-  uint32_t ring[4][NB][RING_CAP / 2];  // two 16-bit payloads per word
-  uint32_t fill[4][NB];
+  uint32_t ring[4][NB + 1][RING_CAP / 2];  // two 16-bit payloads per word; bucket NB is a sink for inactive lanes
+  uint32_t fill[4][NB + 1];
 };
 
 // The one LDS instance per workgroup.  It is reached through this accessor, never through a pointer
@@ -298,45 +307,57 @@ struct ScatterEmit {
   uint32_t* __restrict__ slice_fill;  // [NB][n_waves] entries written (multiple of 64)
   uint32_t* __restrict__ hist;
   uint32_t wave, lane, wave_global;
-  uint32_t my_pos;  // lane b: entries already written to this wave's slice of bucket b
-  uint32_t dbg;     // timing experiments only: bit0 skip the key store, bit1 never flush, bit2 scan only
+  uint32_t my_pos;      // lane b: entries already written to this wave's slice of bucket b
+  uint32_t my_base_lo;  // lane b: address of that slice (kept in registers: no 64-bit multiply per flush)
+  uint32_t my_base_hi;
+  uint32_t dbg;         // timing experiments only: bit0 skip the key store, bit1 never flush, bit2 scan only
 
-  // wave-major layout region[wave][bucket][slice_cap]: the 32 slices a wave writes to sit in ~1 MiB, so a
-  // CU's 16 waves touch a few dozen pages instead of 512 (bucket-major was TLB-bound: 11.9 ms vs 4 ms)
-  __device__ __forceinline__ size_t slice_base(uint32_t b) const {
-    return ((size_t)wave_global * NB + b) * slice_cap;
+  // wave-major layout region[wave][bucket][slice_cap]: the 32 slices a wave writes to sit in ~1 MiB
+  __device__ __forceinline__ void init_cursors() {
+    const uint32_t b = lane < (uint32_t)NB ? lane : 0u;
+    const uint64_t base = reinterpret_cast<uint64_t>(keys + ((size_t)wave_global * NB + b) * slice_cap);
+    my_base_lo = (uint32_t)base;
+    my_base_hi = (uint32_t)(base >> 32);
+    my_pos = 0;
   }
 
-  // write the 64 ring entries starting at ring index g0 (entries >= nvalid become KEY_INVALID) to the slice;
-  // b, g0, nvalid are wave-uniform
+  // write the 64 ring entries starting at ring index g0 to the slice (PARTIAL: entries >= nvalid become
+  // KEY_INVALID); b, g0, nvalid are wave-uniform.  Lanes 0..31 each move two entries (one dword): the group
+  // leaves as one 128-byte line of dword stores.
+  template <bool PARTIAL>
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
-    uint32_t pos = __builtin_amdgcn_readlane(my_pos, b);
-    // lanes 0..31 each move two entries (one dword): the group leaves as one 128-byte line of dword stores
-    uint32_t v = __hip_atomic_load(&scatter_lds<NBITS>().ring[wave][b][((g0 >> 1) + (lane & 31u)) & (RING_CAP / 2 - 1)],
+    const uint32_t pos = __builtin_amdgcn_readlane(my_pos, b);
+    constexpr uint32_t HALF = GROUP / 2;  // lanes that carry a dword
+    uint32_t v = __hip_atomic_load(&scatter_lds<NBITS>().ring[wave][b][((g0 >> 1) + (lane & (HALF - 1u))) & (RING_CAP / 2 - 1)],
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    const uint32_t e0 = 2u * (lane & 31u);
-    if (e0 >= nvalid) v |= 0xFFFFu;  // KEY_INVALID in the low half
-    if (e0 + 1u >= nvalid) v |= 0xFFFF0000u;
-    if (pos + 64u <= slice_cap) {
-      if (lane < 32u && !(dbg & 1u)) reinterpret_cast<uint32_t*>(keys + slice_base(b) + pos)[lane] = v;
-      pos += 64;
-      if (lane == b) my_pos = pos;
-    } else if (lane < 32u) {  // slice full: count these windows directly (rare; keeps skewed inputs correct)
-      if (e0 < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v & 0xFFFFu)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e0 + 1u < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v >> 16)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t e0 = 2u * (lane & (HALF - 1u));
+    if (PARTIAL) {
+      if (e0 >= nvalid) v |= 0xFFFFu;  // KEY_INVALID in the low half
+      if (e0 + 1u >= nvalid) v |= 0xFFFF0000u;
+    }
+    if (pos + (uint32_t)GROUP <= slice_cap) {  // wave-uniform
+      // readlane returns int: widen through uint32_t or the low half sign-extends into the high one
+      const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_base_hi, b) << 32) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_base_lo, b);
+      // the pointer is rebuilt from integers: say "global" explicitly, or the store becomes flat_store (which
+      // also counts on lgkmcnt and stalls the next LDS wait for a full memory round trip)
+      typedef __attribute__((address_space(1))) uint32_t global_u32;
+      global_u32* dst = (global_u32*)(base + 2ull * pos);
+      if (lane < HALF && !(dbg & 1u)) dst[lane] = v;
+      if (lane == b) my_pos = pos + (uint32_t)GROUP;
+    } else if (lane < HALF) {  // slice full: count these windows directly (rare; keeps skewed inputs correct)
+      if (!PARTIAL || e0 < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v & 0xFFFFu)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!PARTIAL || e0 + 1u < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v >> 16)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
   __device__ __forceinline__ void operator()(uint32_t can, bool active) {
-    const uint32_t b = KS::bucket(can);
-    uint32_t slot = 0;
     if (dbg & 4u) active = false;
-    if (active) {
-      ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
-      slot = atomicAdd(&sh.fill[wave][b], 1u);
-      reinterpret_cast<uint16_t*>(&sh.ring[wave][b][0])[slot & (RING_CAP - 1)] = (uint16_t)KS::payload(can);
-    }
-    unsigned long long trig = __ballot(active && (slot & 63u) == 63u);
+    const uint32_t b = active ? KS::bucket(can) : (uint32_t)NB;  // every lane appends; inactive ones to the sink
+    ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
+    const uint32_t slot = atomicAdd(&sh.fill[wave][b], 1u);
+    reinterpret_cast<uint16_t*>(&sh.ring[wave][b][0])[slot & (RING_CAP - 1)] = (uint16_t)KS::payload(can);
+    unsigned long long trig = __builtin_amdgcn_ballot_w64(active && (slot & (uint32_t)(GROUP - 1)) == (uint32_t)(GROUP - 1));
     if (dbg & 2u) trig = 0;
     while (trig) {  // wave-uniform: a ring just completed a group of 64
       const int src = __ffsll((long long)trig) - 1;
@@ -344,7 +365,7 @@ struct ScatterEmit {
       const uint32_t fb = __builtin_amdgcn_readlane(b, src);
       const uint32_t fs = __builtin_amdgcn_readlane(slot, src);
       __builtin_amdgcn_wave_barrier();
-      flush_group(fb, fs - 63u, 64u);
+      flush_group<false>(fb, fs - (uint32_t)(GROUP - 1), (uint32_t)GROUP);
     }
   }
 
@@ -353,8 +374,8 @@ struct ScatterEmit {
     __builtin_amdgcn_wave_barrier();
     for (uint32_t b = 0; b < (uint32_t)NB; ++b) {
       const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().fill[wave][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      const uint32_t r = f & 63u;
-      if (r) flush_group(b, f & ~63u, r);
+      const uint32_t r = f & (uint32_t)(GROUP - 1);
+      if (r) flush_group<true>(b, f & ~(uint32_t)(GROUP - 1), r);
     }
     if (lane < (uint32_t)NB) slice_fill[(size_t)wave_global * NB + lane] = my_pos;
   }
@@ -370,11 +391,12 @@ __global__ __launch_bounds__(256) void count_scatter_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ bg_partials) {
   static_assert(2 * W - NBITS == PAYLOAD_BITS, "payload must be 15 bits");
   ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
-  for (uint32_t i = threadIdx.x; i < 4u * (1u << NBITS); i += blockDim.x) (&sh.fill[0][0])[i] = 0;
+  for (uint32_t i = threadIdx.x; i < 4u * ((1u << NBITS) + 1u); i += blockDim.x) (&sh.fill[0][0])[i] = 0;
   bg_begin<BG>();
   __syncthreads();
   ScatterEmit<W, NBITS> e{keys, slice_cap, gridDim.x * 4u, slice_fill, hist, threadIdx.x >> 6, threadIdx.x & 63u,
-                       blockIdx.x * 4u + (threadIdx.x >> 6), 0u, dbg};
+                          blockIdx.x * 4u + (threadIdx.x >> 6), 0u, 0u, 0u, dbg};
+  e.init_cursors();
   scan_items<W, BOTH, BG>(words32, items, n_items, ltot, defer, e, dbg);
   e.drain();
   bg_end<BG>(bg_partials);
@@ -744,7 +766,7 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
   // grid of pass A: LDS (33 KiB per block at NB = 32) admits 4 blocks per CU
   const uint32_t blocks_needed = (n_items + 255) / 256;
-  const uint32_t max_blocks = (uint32_t)ctx->num_cu * 4u;
+  const uint32_t max_blocks = (uint32_t)ctx->num_cu * (RING_CAP >= 128 ? 4u : 8u);
   const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
   const uint32_t n_waves = blocks * 4u;
   // static slices region[wave][bucket]: expected share + 50 % + slack, in groups of 64 entries
