@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--strand", default="BOTH", choices=["BOTH", "PLUS"])
     ap.add_argument("--pwms", type=int, default=16, help="seed PWMs for the EM phase (whole job)")
     ap.add_argument("--em-iters", type=int, default=10)
+    ap.add_argument("--em-stress-pwms", type=int, default=1000,
+                    help="BASELINE configs[4]: EM-only stress on this many seed PWMs (split over ranks), timed after the steps; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--count-impl", type=int, default=0, help="0 auto, 1 direct atomics, 2 partitioned")
     ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results invalid)")
@@ -163,6 +165,32 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
 
+        # ---- EM-only stress (BASELINE configs[4]): many seed PWMs on the table the last step left -------------
+        em_stress = None
+        if args.em_stress_pwms > 0:
+            n_st = len([i for i in range(args.em_stress_pwms) if i % world == rank])
+            ids = rng.integers(0, NP, size=max(n_st, 1))
+            ps0 = np.full((max(n_st, 1), W, 4), 0.1, np.float32)
+            for j in range(n_st):
+                for q in range(W):
+                    ps0[j, q, (int(ids[j]) >> (2 * q)) & 3] = 0.7
+            ps_init = torch.from_numpy(ps0).to(dev)
+            ps = torch.empty_like(ps_init)
+            st_state = torch.zeros((max(n_st, 1), 2), dtype=torch.int32, device=dev)
+            st_change = torch.zeros(max(n_st, 1), dtype=torch.float32, device=dev)
+            t_a, t_b = ctx.timer(), ctx.timer()
+            best = None
+            for rep in range(3):
+                ps.copy_(ps_init)
+                ctx.record(t_a)
+                if n_st:
+                    pk._check(lib.pengk_em_device(ctx.h, W, n_st, ps.data_ptr(), 1e4, 0.0, args.em_iters, counts.data_ptr(),
+                                                  bgprob[K].data_ptr(), st_state.data_ptr(), st_change.data_ptr()))
+                ctx.record(t_b)
+                ms = ctx.elapsed_ms(t_a, t_b)
+                best = ms if best is None else min(best, ms)
+            em_stress = (n_st, best)
+
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,6 +221,10 @@ def main():
                 "zscores_per_s": round(NP / (sweep_ms * 1e-3), 1) if sweep_ms else None,
                 "em_evals_per_s_per_gpu": round(n_my * args.em_iters * NP / (em_ms * 1e-3), 1) if em_ms and n_my else None,
                 "count_ms": round(count_ms, 4), "sweep_ms": round(sweep_ms, 4), "em_ms": round(em_ms, 4),
+                "em_stress_pwms_per_gpu": em_stress[0] if em_stress else None,
+                "em_stress_ms": round(em_stress[1], 4) if em_stress else None,
+                "em_stress_evals_per_s_per_gpu": round(em_stress[0] * args.em_iters * NP / (em_stress[1] * 1e-3), 1)
+                if em_stress and em_stress[1] else None,
             },
             "roofline": {"kernel": "pengk_count_bg = count_scatter_kernel<%d,%s> + count_hist_kernel + count_gather_kernel (K1, K1b fused)"
                                    % (W, "both" if both else "plus") if W in (8, 10) and args.count_impl != 1
