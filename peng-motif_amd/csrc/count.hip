@@ -271,8 +271,30 @@ struct KeySplit {
   static constexpr uint32_t NB = 1u << NBITS;
   __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> S) & (NB - 1u); }
   __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & LOW) | ((id >> (S + NBITS)) << S); }
-  __host__ __device__ static inline uint32_t join(uint32_t b, uint32_t p) {
+  __host__ __device__ static inline uint32_t join(uint32_t b, uint32_t p, uint32_t /*outer*/ = 0) {
     return (p & LOW) | (b << S) | ((p >> S) << (S + NBITS));
+  }
+};
+
+// W = 12 (24-bit ids) needs 2^9 buckets of 2^15 bins: two levels.
+//   level 1: bucket1 = id bits [8,13), 19-bit payload1 = the rest squeezed together (32-bit keys)
+//   level 2: bucket2 = payload1 bits [8,12), 15-bit payload2 = the rest (16-bit keys)
+// Again the bucket bits come from the middle of the id (see KeySplit).
+struct Split12L1 {
+  static constexpr uint32_t NB = 32;
+  __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> 8) & 31u; }
+  __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & 0xFFu) | ((id >> 13) << 8); }
+  __host__ __device__ static inline uint32_t join(uint32_t b1, uint32_t p1) { return (p1 & 0xFFu) | (b1 << 8) | ((p1 >> 8) << 13); }
+};
+struct Split12L2 {
+  static constexpr int NBITS = 4;
+  static constexpr uint32_t NB = 16;
+  __host__ __device__ static inline uint32_t bucket(uint32_t p1) { return (p1 >> 8) & 15u; }
+  __host__ __device__ static inline uint32_t payload(uint32_t p1) { return (p1 & 0xFFu) | ((p1 >> 12) << 8); }
+  // (bucket2, payload2) of level-1 bucket `outer` -> 24-bit id
+  __host__ __device__ static inline uint32_t join(uint32_t b2, uint32_t p2, uint32_t outer) {
+    const uint32_t p1 = (p2 & 0xFFu) | (b2 << 8) | ((p2 >> 8) << 12);
+    return Split12L1::join(outer, p1);
   }
 };
 
@@ -296,9 +318,8 @@ __device__ __forceinline__ ScatterShared<NBITS>& scatter_lds() {
 // b lives in the registers of lane b (read with v_readlane), ring counters are LDS atomics, and ring
 // payloads written by other lanes are read through a volatile pointer.  (A first version kept the
 // cursors in plain LDS words written by lane 0: the compiler legally re-used each lane's stale copy.)
-template <int W, int NBITS>
+template <class KS, int NBITS>
 struct ScatterEmit {
-  using KS = KeySplit<W, NBITS>;
   static constexpr int NB = 1 << NBITS;
   static_assert(NB <= 64, "one lane per bucket holds its write cursor");
   uint16_t* __restrict__ keys;
@@ -311,6 +332,7 @@ struct ScatterEmit {
   uint32_t my_base_lo;  // lane b: address of that slice (kept in registers: no 64-bit multiply per flush)
   uint32_t my_base_hi;
   uint32_t dbg;         // timing experiments only: bit0 skip the key store, bit1 never flush, bit2 scan only
+  uint32_t outer;       // level-1 bucket these keys came from (two-level partition); 0 otherwise
 
   // wave-major layout region[wave][bucket][slice_cap]: the 32 slices a wave writes to sit in ~1 MiB
   __device__ __forceinline__ void init_cursors() {
@@ -346,8 +368,8 @@ struct ScatterEmit {
       if (lane < HALF && !(dbg & 1u)) dst[lane] = v;
       if (lane == b) my_pos = pos + (uint32_t)GROUP;
     } else if (lane < HALF) {  // slice full: count these windows directly (rare; keeps skewed inputs correct)
-      if (!PARTIAL || e0 < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v & 0xFFFFu)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!PARTIAL || e0 + 1u < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v >> 16)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!PARTIAL || e0 < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v & 0xFFFFu, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!PARTIAL || e0 + 1u < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v >> 16, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -394,25 +416,152 @@ __global__ __launch_bounds__(256) void count_scatter_kernel(const uint32_t* __re
   for (uint32_t i = threadIdx.x; i < 4u * ((1u << NBITS) + 1u); i += blockDim.x) (&sh.fill[0][0])[i] = 0;
   bg_begin<BG>();
   __syncthreads();
-  ScatterEmit<W, NBITS> e{keys, slice_cap, gridDim.x * 4u, slice_fill, hist, threadIdx.x >> 6, threadIdx.x & 63u,
-                          blockIdx.x * 4u + (threadIdx.x >> 6), 0u, 0u, 0u, dbg};
+  ScatterEmit<KeySplit<W, NBITS>, NBITS> e{keys, slice_cap, gridDim.x * 4u, slice_fill, hist, threadIdx.x >> 6,
+                                           threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6), 0u, 0u, 0u, dbg, 0u};
   e.init_cursors();
   scan_items<W, BOTH, BG>(words32, items, n_items, ltot, defer, e, dbg);
   e.drain();
   bg_end<BG>(bg_partials);
 }
 
+// ---- two-level partition (W = 12) -----------------------------------------------------------------------
+// Level 1: same scan; 32-bit keys (19-bit payload1) into 32 wave-private rings of 64 entries; a ring that
+// completes 32 entries leaves as one 128-byte line (32 lanes x dword) into region1[wave][bucket1][cap1].
+constexpr int RING32_CAP = 64;
+constexpr int GROUP32 = 32;
+constexpr uint32_t KEY32_INVALID = 0xFFFFFFFFu;
+
+struct Scatter32Shared {
+  uint32_t ring[4][33][RING32_CAP];
+  uint32_t fill[4][33];
+};
+__device__ __forceinline__ Scatter32Shared& scatter32_lds() {
+  __shared__ Scatter32Shared sh;
+  return sh;
+}
+
+struct Scatter32Emit {
+  uint32_t* __restrict__ keys;
+  uint32_t slice_cap;  // entries per (wave, bucket1) slice, multiple of GROUP32
+  uint32_t* __restrict__ slice_fill;
+  uint32_t* __restrict__ hist;
+  uint32_t wave, lane, wave_global;
+  uint32_t my_pos, my_base_lo, my_base_hi;
+
+  __device__ __forceinline__ void init_cursors() {
+    const uint32_t b = lane < 32u ? lane : 0u;
+    const uint64_t base = reinterpret_cast<uint64_t>(keys + ((size_t)wave_global * 32u + b) * slice_cap);
+    my_base_lo = (uint32_t)base;
+    my_base_hi = (uint32_t)(base >> 32);
+    my_pos = 0;
+  }
+
+  __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
+    const uint32_t pos = __builtin_amdgcn_readlane(my_pos, b);
+    uint32_t v = __hip_atomic_load(&scatter32_lds().ring[wave][b][(g0 + (lane & 31u)) & (RING32_CAP - 1)], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if ((lane & 31u) >= nvalid) v = KEY32_INVALID;
+    if (pos + (uint32_t)GROUP32 <= slice_cap) {
+      const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_base_hi, b) << 32) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_base_lo, b);
+      typedef __attribute__((address_space(1))) uint32_t global_u32;
+      global_u32* dst = (global_u32*)(base + 4ull * pos);
+      if (lane < 32u) dst[lane] = v;
+      if (lane == b) my_pos = pos + (uint32_t)GROUP32;
+    } else if (lane < 32u && v != KEY32_INVALID) {  // slice full: count directly
+      __hip_atomic_fetch_add(&hist[Split12L1::join(b, v)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  __device__ __forceinline__ void operator()(uint32_t can, bool active) {
+    const uint32_t b = active ? Split12L1::bucket(can) : 32u;
+    Scatter32Shared& sh = scatter32_lds();
+    const uint32_t slot = atomicAdd(&sh.fill[wave][b], 1u);
+    sh.ring[wave][b][slot & (RING32_CAP - 1)] = Split12L1::payload(can);
+    unsigned long long trig = __builtin_amdgcn_ballot_w64(active && (slot & (uint32_t)(GROUP32 - 1)) == (uint32_t)(GROUP32 - 1));
+    while (trig) {
+      const int src = __ffsll((long long)trig) - 1;
+      trig &= trig - 1;
+      const uint32_t fb = __builtin_amdgcn_readlane(b, src);
+      const uint32_t fs = __builtin_amdgcn_readlane(slot, src);
+      __builtin_amdgcn_wave_barrier();
+      flush_group(fb, fs - (uint32_t)(GROUP32 - 1), (uint32_t)GROUP32);
+    }
+  }
+
+  __device__ __forceinline__ void drain() {
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t b = 0; b < 32u; ++b) {
+      const uint32_t f = __hip_atomic_load(&scatter32_lds().fill[wave][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const uint32_t r = f & (uint32_t)(GROUP32 - 1);
+      if (r) flush_group(b, f & ~(uint32_t)(GROUP32 - 1), r);
+    }
+    if (lane < 32u) slice_fill[(size_t)wave_global * 32u + lane] = my_pos;
+  }
+};
+
+template <bool BOTH, bool BG>
+__global__ __launch_bounds__(256) void count_scatter12_kernel(const uint32_t* __restrict__ words32,
+                                                              const uint64_t* __restrict__ items, uint32_t n_items,
+                                                              uint32_t* __restrict__ keys, uint32_t slice_cap,
+                                                              uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
+                                                              unsigned long long* __restrict__ ltot,
+                                                              uint32_t* __restrict__ defer, uint32_t* __restrict__ bg_partials) {
+  Scatter32Shared& sh = scatter32_lds();
+  for (uint32_t i = threadIdx.x; i < 4u * 33u; i += blockDim.x) (&sh.fill[0][0])[i] = 0;
+  bg_begin<BG>();
+  __syncthreads();
+  Scatter32Emit e{keys, slice_cap, slice_fill, hist, threadIdx.x >> 6, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6),
+                  0u, 0u, 0u};
+  e.init_cursors();
+  scan_items<12, BOTH, BG>(words32, items, n_items, ltot, defer, e);
+  e.drain();
+  bg_end<BG>(bg_partials);
+}
+
+// Level 2: a workgroup belongs to ONE level-1 bucket (blockIdx.x / bpb1); its waves stream that bucket's
+// level-1 slices (64 keys per step, one per lane) and re-scatter them by bucket2 into 16 wave-private rings
+// -> region2[wave2][bucket2][cap2] (16-bit payload2), exactly like pass A of the one-level scheme.
+__global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* __restrict__ keys1, uint32_t cap1,
+                                                                const uint32_t* __restrict__ fill1, uint32_t n_slices1,
+                                                                uint32_t bpb1, uint16_t* __restrict__ keys2, uint32_t cap2,
+                                                                uint32_t* __restrict__ fill2, uint32_t* __restrict__ hist) {
+  ScatterShared<4>& sh = scatter_lds<4>();
+  for (uint32_t i = threadIdx.x; i < 4u * 17u; i += blockDim.x) (&sh.fill[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t b1 = blockIdx.x / bpb1, j = blockIdx.x % bpb1;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  ScatterEmit<Split12L2, 4> e{keys2, cap2, gridDim.x * 4u, fill2, hist, wave, lane, blockIdx.x * 4u + wave, 0u, 0u, 0u, 0u, b1};
+  e.init_cursors();
+  const uint32_t per = (n_slices1 + bpb1 - 1) / bpb1;
+  const uint32_t first = j * per, last = min(n_slices1, first + per);
+  for (uint32_t s = first + wave; s < last; s += 4) {
+    const uint32_t n = fill1[(size_t)s * 32u + b1];  // multiple of GROUP32
+    const uint32_t* src = keys1 + ((size_t)s * 32u + b1) * cap1;
+    for (uint32_t i = 0; i < n; i += 64) {  // wave-uniform trip count
+      const uint32_t k = (i + lane < n) ? src[i + lane] : KEY32_INVALID;
+      e(k, k != KEY32_INVALID);
+    }
+  }
+  e.drain();
+}
+
 // One workgroup = 16 waves = part of one bucket: waves walk the (bucket, producer-wave) slices of their share.
 __global__ __launch_bounds__(1024) void count_hist_kernel(const uint16_t* __restrict__ keys, uint32_t slice_cap,
                                                           uint32_t n_slices, uint32_t nb,
                                                           const uint32_t* __restrict__ slice_fill, uint32_t bpb,
-                                                          uint32_t* __restrict__ temp) {
+                                                          uint32_t* __restrict__ temp, uint32_t slices_per_outer) {
   extern __shared__ uint32_t h[];  // 2^15 bins
-  const uint32_t b = blockIdx.x / bpb, j = blockIdx.x % bpb;
+  // one level: fine bucket f = b, its slices are all producer waves.  Two levels (slices_per_outer > 0):
+  // f = b1 * nb + b2, its slices are the producer waves of the level-2 workgroups that served b1.
+  const uint32_t f = blockIdx.x / bpb, j = blockIdx.x % bpb;
+  const uint32_t b = slices_per_outer ? f % nb : f;
+  const uint32_t slice0 = slices_per_outer ? (f / nb) * slices_per_outer : 0u;
+  if (slices_per_outer) n_slices = slices_per_outer;
   for (uint32_t i = threadIdx.x; i < (1u << PAYLOAD_BITS); i += blockDim.x) h[i] = 0;
   __syncthreads();
   const uint32_t per = (n_slices + bpb - 1) / bpb;
-  const uint32_t first = j * per, last = min(n_slices, first + per);
+  const uint32_t first = slice0 + j * per, last = slice0 + min(n_slices, j * per + per);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   for (uint32_t s = first + wave; s < last; s += 16) {
     const uint32_t n8 = slice_fill[(size_t)s * nb + b] >> 3;  // groups of 8 keys (16 B); fill is a multiple of 64
@@ -426,10 +575,21 @@ __global__ __launch_bounds__(1024) void count_hist_kernel(const uint16_t* __rest
     }
   }
   __syncthreads();
-  uint32_t* dst = temp + ((size_t)b << PAYLOAD_BITS);
+  uint32_t* dst = temp + ((size_t)f << PAYLOAD_BITS);
   for (uint32_t i = threadIdx.x; i < (1u << PAYLOAD_BITS); i += blockDim.x) {
     const uint32_t v = h[i];
     if (v) __hip_atomic_fetch_add(&dst[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// W = 12: table[id] += temp[bucket1 * 16 + bucket2][payload2]
+__global__ __launch_bounds__(256) void count_gather12_kernel(const uint32_t* __restrict__ temp, uint32_t* __restrict__ hist) {
+  const uint32_t np = 1u << 24;
+  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
+    const uint32_t p1 = Split12L1::payload(x);
+    const uint32_t fb = Split12L1::bucket(x) * 16u + Split12L2::bucket(p1);
+    const uint32_t v = temp[((size_t)fb << PAYLOAD_BITS) | Split12L2::payload(p1)];
+    if (v) hist[x] += v;
   }
 }
 
@@ -815,10 +975,81 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   if (bpb > n_waves) bpb = n_waves;
   if (bpb < 1) bpb = 1;
   hipLaunchKernelGGL(count_hist_kernel, dim3(NB * bpb), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys, slice_cap, n_waves,
-                     NB, slice_fill, bpb, temp);
+                     NB, slice_fill, bpb, temp, 0u);
   PENGK_HIP(hipGetLastError());
   const uint32_t gb = (np + 255) / 256 < 2048u ? (np + 255) / 256 : 2048u;
   hipLaunchKernelGGL((count_gather_kernel<W, NBITS>), dim3(gb), dim3(256), 0, ctx->stream, temp, np, d_counts);
+  PENGK_HIP(hipGetLastError());
+  return PENGK_OK;
+}
+
+// W = 12: scan -> 32 coarse buckets of 32-bit keys -> 16 fine buckets each of 16-bit keys -> 512 LDS histograms
+int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items, uint64_t* d_bg) {
+  const uint32_t np = 1u << 24;
+  const uint32_t* w32 = (const uint32_t*)ctx->d_words;
+  const uint32_t blocks_needed = (n_items + 255) / 256;
+  const uint32_t max_blocks = (uint32_t)ctx->num_cu * 4u;
+  const uint32_t blocks1 = blocks_needed < max_blocks ? blocks_needed : max_blocks;
+  const uint32_t n_waves1 = blocks1 * 4u;
+  const uint64_t windows = ctx->n_windows_hint ? ctx->n_windows_hint : ctx->n_items * (uint64_t)ctx->item_windows;
+  // level-1 slices
+  uint64_t share1 = windows / (32ull * n_waves1);
+  uint64_t cap1_64 = share1 + share1 / 2 + 256;
+  if (ctx->key_cap_override) cap1_64 = ctx->key_cap_override;
+  cap1_64 = (cap1_64 + 63) / 64 * 64;
+  // level-2 grid: bpb1 workgroups per level-1 bucket
+  uint32_t bpb1 = ((uint32_t)ctx->num_cu * 8u + 31u) / 32u;
+  if (bpb1 > n_waves1) bpb1 = n_waves1;
+  if (bpb1 < 1) bpb1 = 1;
+  const uint32_t blocks2 = 32u * bpb1;
+  const uint32_t n_waves2 = blocks2 * 4u;
+  uint64_t share2 = windows / (16ull * n_waves2);
+  uint64_t cap2_64 = share2 + share2 / 2 + 512;
+  if (ctx->key_cap_override) cap2_64 = ctx->key_cap_override;
+  cap2_64 = (cap2_64 + 63) / 64 * 64;
+  if (cap1_64 >= (1ull << 31) || cap2_64 >= (1ull << 31)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
+  const uint32_t cap1 = (uint32_t)cap1_64, cap2 = (uint32_t)cap2_64;
+  const size_t bytes1 = (size_t)n_waves1 * 32u * cap1 * sizeof(uint32_t);
+  const size_t bytes2 = (size_t)n_waves2 * 16u * cap2 * sizeof(uint16_t);
+  int rc = ensure_scratch(ctx, &ctx->d_keys, &ctx->keys_bytes, bytes1 + bytes2);
+  if (rc) return rc;
+  uint32_t* keys1 = (uint32_t*)ctx->d_keys;
+  uint16_t* keys2 = (uint16_t*)((char*)ctx->d_keys + bytes1);
+  const size_t fill1_words = ((size_t)n_waves1 * 32u + 63) / 64 * 64, fill2_words = ((size_t)n_waves2 * 16u + 63) / 64 * 64;
+  const size_t aux_need = (fill1_words + fill2_words + (size_t)np) * sizeof(uint32_t);
+  rc = ensure_scratch(ctx, &ctx->d_count_aux, &ctx->count_aux_bytes, aux_need);
+  if (rc) return rc;
+  uint32_t* fill1 = (uint32_t*)ctx->d_count_aux;
+  uint32_t* fill2 = fill1 + fill1_words;
+  uint32_t* temp = fill2 + fill2_words;
+  PENGK_HIP(hipMemsetAsync(ctx->d_count_aux, 0, aux_need, ctx->stream));
+  unsigned long long* lt = (unsigned long long*)d_ltot;
+  uint32_t* bgp = nullptr;
+  if (d_bg) {
+    rc = bg_partials_buffer(ctx, blocks1, &bgp);
+    if (rc) return rc;
+  }
+#define TA_S12(B, G) B, G
+  PENGK_LAUNCH_BB(count_scatter12_kernel, TA_S12, both, d_bg != nullptr, dim3(blocks1), dim3(256), w32, ctx->d_items, n_items, keys1,
+                  cap1, fill1, d_counts, lt, ctx->d_defer, bgp);
+#undef TA_S12
+  PENGK_HIP(hipGetLastError());
+  if (d_bg) {
+    rc = bg_finish_fused(ctx, blocks1, d_bg);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(count_rescatter12_kernel, dim3(blocks2), dim3(256), 0, ctx->stream, keys1, cap1, fill1, n_waves1, bpb1, keys2,
+                     cap2, fill2, d_counts);
+  PENGK_HIP(hipGetLastError());
+  static bool attr_set = false;
+  if (!attr_set) {
+    PENGK_HIP(hipFuncSetAttribute((const void*)count_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << PAYLOAD_BITS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(count_hist_kernel, dim3(512), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys2, cap2, n_waves2, 16u, fill2, 1u,
+                     temp, bpb1 * 4u);
+  PENGK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(count_gather12_kernel, dim3(4096), dim3(256), 0, ctx->stream, temp, d_counts);
   PENGK_HIP(hipGetLastError());
   return PENGK_OK;
 }
@@ -831,11 +1062,14 @@ int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_lto
     return PENGK_OK;
   }
   int impl = ctx->count_impl;
-  constexpr bool can_partition = (W == 8 || W == 10);
+  constexpr bool can_partition = (W == 8 || W == 10 || W == 12);
   if (impl == 0) impl = can_partition ? 2 : 1;
-  if (impl == 2 && !can_partition) return fail(PENGK_ERR_UNSUPPORTED, "partitioned count is built for W = 8 and 10 only");
+  if (impl == 2 && !can_partition) return fail(PENGK_ERR_UNSUPPORTED, "partitioned count is built for W = 8, 10 and 12 only");
   int rc;
-  if constexpr (can_partition) {
+  if constexpr (W == 12) {
+    rc = impl == 2 ? launch_partition12(ctx, both, d_counts, d_ltot, n_items, d_bg)
+                   : launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items, d_bg);
+  } else if constexpr (can_partition) {
     rc = impl == 2 ? launch_partition_w<W>(ctx, both, d_counts, d_ltot, n_items, d_bg)
                    : launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items, d_bg);
   } else {

@@ -132,6 +132,43 @@ def test_count_both_implementations(ctx, golden_dir, name, impl):
         ctx.set_option("count_impl", 0)
 
 
+@pytest.mark.parametrize("both", [True, False])
+def test_w12_two_level_partition(ctx, both):
+    """W = 12: scan -> 32 coarse buckets (32-bit keys) -> 16 fine buckets (16-bit keys) -> 512 LDS histograms;
+    against the oracle on a small set and against the direct-atomic emitter on a larger one, incl. fused K1b,
+    split items and an overflowing key buffer."""
+    W = 12
+    codes, offs = po.synth(5, 0, 4000, 150)
+    want, ltot = po.count(codes, offs, W, both)
+    for M, cap in ((0, 0), (64, 0), (0, 64)):
+        p = pk.Packed(codes, offs, W, M)
+        ctx.upload(p)
+        ctx.set_option("count_impl", 2)
+        ctx.set_option("key_cap_override", cap)
+        try:
+            counts, lt, bg = ctx.count_bg(both)
+            if both:
+                ctx.mirror(W, counts)
+            assert int(lt.to_host()[0]) == ltot
+            assert np.array_equal(counts.to_host().astype(np.uint64), want), (M, cap)
+            assert np.array_equal(bg.to_host().astype(np.int64), po.bg_counts(codes, offs, 2))
+        finally:
+            ctx.set_option("count_impl", 0)
+            ctx.set_option("key_cap_override", 0)
+    n = 400_000
+    ctx.synth(1, 77, n, 200, W)
+    ctx.set_option("count_impl", 1)
+    d, ld = ctx.count(both)
+    d = d.to_host()
+    ctx.set_option("count_impl", 2)
+    try:
+        q, lq = ctx.count(both)
+        assert int(ld.to_host()[0]) == int(lq.to_host()[0]) == n * (200 - W + 1)
+        assert np.array_equal(d, q.to_host())
+    finally:
+        ctx.set_option("count_impl", 0)
+
+
 def test_partitioned_count_survives_a_full_bucket_region(ctx):
     """Skew: every counted window lands in few buckets and the key-buffer hint is far too small, so bucket
     regions run full and the overflow path (direct atomics) must keep the table exact."""
