@@ -20,10 +20,13 @@
 namespace pengk {
 namespace {
 
-template <int W>
+// HIMAX = 4: 256 leaves per thread (fewest partial products; best when the grid is full anyway).
+// HIMAX = 2: 16 leaves per thread, 16x more workgroups -- for small PWM batches that would otherwise leave
+// most CUs with a single wave (the 16-PWM batch of a typical run).
+template <int W, int HIMAX = 4>
 struct EmGeo {
   static constexpr int LO = 4;                               // digits taken from threadIdx (256 threads)
-  static constexpr int HI = (W - LO) < 4 ? (W - LO) : 4;     // digits walked per thread
+  static constexpr int HI = (W - LO) < HIMAX ? (W - LO) : HIMAX;  // digits walked per thread
   static constexpr int MID = W - LO - HI;                    // digits taken from blockIdx.x
   static constexpr int PB = LO + MID;                        // first HI position
   static constexpr int NB = 1 << (2 * MID);                  // blocks per PWM
@@ -36,12 +39,12 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // lane 0 holds the sum; fixed tree => deterministic
 }
 
-template <int W>
+template <int W, int HIMAX>
 __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
                                                             const uint32_t* __restrict__ counts,
                                                             const float* __restrict__ bg, float saturation,
                                                             double* __restrict__ partials) {
-  using G = EmGeo<W>;
+  using G = EmGeo<W, HIMAX>;
   const int pw = blockIdx.y;
   if (state[2 * pw + 1] == 0) return;  // converged or out of iterations (block-uniform)
 
@@ -158,11 +161,11 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 
 // One block per PWM: sum the per-block partials in block order, then the reference's float32
 // epilogue: normalise rows (:129), change = sum |new - old| (:132-137), swap (:140-143).
-template <int W>
+template <int W, int HIMAX>
 __global__ __launch_bounds__(64) void em_finalize_kernel(float* __restrict__ pwms, int32_t* __restrict__ state,
                                                          float* __restrict__ change_out, const double* __restrict__ partials,
                                                          float threshold, int max_it) {
-  using G = EmGeo<W>;
+  using G = EmGeo<W, HIMAX>;
   const int pw = blockIdx.x;
   if (state[2 * pw + 1] == 0) return;
   __shared__ float s_new[W * 4];
@@ -204,10 +207,10 @@ __global__ void em_init_kernel(int n, int W, float threshold, int max_it, int32_
   change[i] = c0;
 }
 
-template <int W>
-int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
-             const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
-  using G = EmGeo<W>;
+template <int W, int HIMAX>
+int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
+               const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
+  using G = EmGeo<W, HIMAX>;
   hipLaunchKernelGGL(em_init_kernel, dim3((unsigned)((n_pwm + 255) / 256)), dim3(256), 0, ctx->stream, (int)n_pwm, W, threshold,
                      max_it, d_state, d_change);
   PENGK_HIP(hipGetLastError());
@@ -222,14 +225,26 @@ int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, flo
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
     for (int it = 0; it < max_it; ++it) {
-      hipLaunchKernelGGL((em_accumulate_kernel<W>), dim3(G::NB, (unsigned)nb), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL((em_accumulate_kernel<W, HIMAX>), dim3(G::NB, (unsigned)nb), dim3(256), 0, ctx->stream,
                          d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_partials);
-      hipLaunchKernelGGL((em_finalize_kernel<W>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
-                         d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it);
+      hipLaunchKernelGGL((em_finalize_kernel<W, HIMAX>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
+                         d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it);
     }
     PENGK_HIP(hipGetLastError());
   }
   return PENGK_OK;
+}
+
+template <int W>
+int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
+             const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
+  // few PWMs: more, smaller workgroups so that every CU gets several waves
+  if constexpr (W >= 8) {
+    const int64_t wg4 = n_pwm * EmGeo<W, 4>::NB;
+    if (wg4 < (int64_t)ctx->num_cu * 8)
+      return launch_geo<W, 2>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
+  }
+  return launch_geo<W, 4>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
 }
 
 }  // namespace
