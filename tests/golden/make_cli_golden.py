@@ -18,6 +18,9 @@ CASES = {
     "cli_mafk_w10": ("MafK.fasta", ["-w", "10"]),                                    # BASELINE config 2
     "cli_mafk_w10_plus": ("MafK.fasta", ["-w", "10", "--strand", "PLUS"]),
     "cli_torture_w6": ("torture.fa", ["-w", "6", "-t", "3", "--count-threshold", "2"]),
+    "cli_mafk100_w8_bg1_enrich": ("MafK_100seqs.fasta", ["-w", "8", "--bg-model-order", "1", "--optimization_score", "ENRICHMENT", "-t", "6"]),
+    "cli_mafk_w10_bg0_nofilter": ("MafK.fasta", ["-w", "10", "--bg-model-order", "0", "--no-neighbor-filtering", "--max-optimized-patterns", "12",
+                                                  "--use-default-pwm", "--em-max-iterations", "3", "-a", "500", "--pseudo-counts", "20"]),
 }
 
 

@@ -23,7 +23,7 @@ SELFTEST = os.path.join(HOST, "host_selftest")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 CASES = ["cli_mafk100_w8", "cli_mafk100_w6_plus_noem", "cli_mafk100_w8_logpval_nomerge", "cli_mafk_w10", "cli_mafk_w10_plus",
-         "cli_torture_w6"]
+         "cli_torture_w6", "cli_mafk100_w8_bg1_enrich", "cli_mafk_w10_bg0_nofilter"]
 
 
 def parse_meme(path):

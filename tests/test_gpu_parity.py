@@ -97,6 +97,27 @@ def test_count_and_sweep_bit_exact(ctx, golden_dir, name):
     assert bits_equal(seeds, r["g"]["seeds"])
 
 
+@pytest.mark.parametrize("k", [0, 1])
+@pytest.mark.parametrize("name", ["mafk100_w8_both", "torture_w6_plus"])
+def test_sweep_lower_background_orders(ctx, golden_dir, name, k):
+    """--bg-model-order 0 / 1: z-scores use order k while all orders 0..max_k are tabulated (EM uses max_k)."""
+    r = cpu_pipeline(golden_dir, name)
+    W, both = r["W"], r["both"]
+    p = pk.Packed(r["codes"], r["offs"], W)
+    ctx.upload(p)
+    counts, ltot = ctx.count(both)
+    if both:
+        ctx.mirror(W, counts)
+    V = ctx.bg_model(ctx.to_device(p.bg_counts.astype(np.uint64)), 2)
+    bgprob, expected, logp, z = ctx.pattern_stats(W, both, k, 2, V, ltot, counts)
+    e, lp, zz = po.stats(W, r["counts"], r["bgp"][k], r["ltot"])
+    bgp = bgprob.to_host()
+    for o in range(3):
+        assert bits_equal(bgp[o], r["bgp"][o])
+    assert bits_equal(expected.to_host(), e) and bits_equal(z.to_host(), zz)
+    assert ulp_diff(logp.to_host(), lp) <= 1
+
+
 @pytest.mark.parametrize("name", ["torture_w6_both", "torture_w6_plus", "torture_w8_plus", "mafk100_w8_both"])
 def test_count_with_split_items_and_deferred_fixup(ctx, golden_dir, name):
     """item_windows = 64 splits every run longer than 64 windows: poly-A / (AT)n / tandem repeats force
