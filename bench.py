@@ -63,8 +63,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # PENGK_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
+        # (ranks share devices, collectives go through the host).  The measured runs use nccl (= RCCL).
+        backend = os.environ.get("PENGK_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -192,7 +200,7 @@ def main():
             em_stress = (n_st, best)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

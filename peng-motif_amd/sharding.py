@@ -31,6 +31,7 @@ def check_global_bin_bound(local_bound, dist=None):
         if dist.get_backend() == "nccl":
             t = t.cuda()
         dist.all_reduce(t)
+        t = t.cpu()
     total = int(t.item())
     if total >= 2 ** 32:
         raise OverflowError("a count bin could reach %d >= 2^32 across ranks; use fewer sequences per job" % total)
@@ -43,5 +44,12 @@ def allreduce_tables(counts_i32, scalars_i64, dist=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return
     assert counts_i32.dtype == torch.int32 and scalars_i64.dtype == torch.int64
+    if dist.get_backend() == "gloo" and counts_i32.is_cuda:  # rehearsal path: gloo reduces host copies
+        c, s = counts_i32.cpu(), scalars_i64.cpu()
+        dist.all_reduce(c)
+        dist.all_reduce(s)
+        counts_i32.copy_(c)
+        scalars_i64.copy_(s)
+        return
     dist.all_reduce(counts_i32)
     dist.all_reduce(scalars_i64)
