@@ -48,7 +48,6 @@ def main():
                     help="BASELINE configs[4]: EM-only stress on this many seed PWMs (split over ranks), timed after the steps; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--count-impl", type=int, default=0, help="0 auto, 1 direct atomics, 2 partitioned")
-    ap.add_argument("--debug-flags", type=int, default=0, help="timing experiments only (results invalid)")
     ap.add_argument("--cpu-sample-seqs", type=int, default=6_000_000)
     args = ap.parse_args()
 
@@ -88,8 +87,6 @@ def main():
     lib = pk.lib()
     pk._check(lib.pengk_set_stream(ctx.h, ctx_stream.cuda_stream))  # kernels + collectives share one stream
     ctx.set_option("count_impl", args.count_impl)
-    if args.debug_flags:
-        ctx.set_option("debug_flags", args.debug_flags)
 
     with torch.cuda.stream(ctx_stream):
         # ---- resident input: this rank's shard of the global synthetic set -------------------------

@@ -112,10 +112,6 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     ctx->count_impl = (int)value;
     return PENGK_OK;
   }
-  if (strcmp(name, "debug_flags") == 0) {
-    ctx->debug_flags = (uint64_t)value;
-    return PENGK_OK;
-  }
   if (strcmp(name, "key_cap_override") == 0) {
     ctx->key_cap_override = (uint64_t)value;
     return PENGK_OK;

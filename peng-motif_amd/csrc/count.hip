@@ -91,7 +91,7 @@ __device__ __forceinline__ void bg_end(uint32_t* __restrict__ bg_partials) {
 template <int W, bool BOTH, bool BG, class Emit>
 __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32, const uint64_t* __restrict__ items,
                                            uint32_t n_items, unsigned long long* __restrict__ ltot,
-                                           uint32_t* __restrict__ defer, Emit& emit, uint32_t dbg = 0) {
+                                           uint32_t* __restrict__ defer, Emit& emit) {
   using G = Geo<W>;
   const BgCount<W, BG> bgc{threadIdx.x >> 6};
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,7 +182,7 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
     for (uint32_t t0 = 0; t0 < nw_max; t0 += 16) {
       const uint32_t hi = nxt;
       ++wi;
-      nxt = (t0 + 16u < nw_scan) ? ((dbg & 16u) ? hi * 2654435761u + t0 : words32[wi + 1]) : 0u;  // dbg: no loads in the loop
+      nxt = (t0 + 16u < nw_scan) ? words32[wi + 1] : 0u;
       const uint32_t chunk = funnel(hi, lo, shift);
       lo = hi;
 #pragma unroll
@@ -322,84 +322,93 @@ template <class KS, int NBITS>
 struct ScatterEmit {
   static constexpr int NB = 1 << NBITS;
   static_assert(NB <= 64, "one lane per bucket holds its write cursor");
+  static_assert(GROUP == 64, "a group is one 2-byte store per lane");
+  typedef __attribute__((address_space(1))) uint16_t global_u16;
   uint16_t* __restrict__ keys;
-  uint32_t slice_cap;  // entries per (bucket, wave) slice, multiple of 64
-  uint32_t n_waves;    // waves of the grid
-  uint32_t* __restrict__ slice_fill;  // [NB][n_waves] entries written (multiple of 64)
+  uint32_t slice_cap;  // entries per (wave, bucket) slice, multiple of 64
+  uint32_t* __restrict__ slice_fill;  // [n_waves][NB] entries written (multiple of 64)
   uint32_t* __restrict__ hist;
   uint32_t wave, lane, wave_global;
-  uint32_t my_pos;      // lane b: entries already written to this wave's slice of bucket b
-  uint32_t my_base_lo;  // lane b: address of that slice (kept in registers: no 64-bit multiply per flush)
-  uint32_t my_base_hi;
-  uint32_t dbg;         // timing experiments only: bit0 skip the key store, bit1 never flush, bit2 scan only
-  uint32_t outer;       // level-1 bucket these keys came from (two-level partition); 0 otherwise
+  uint32_t outer;     // level-1 bucket these keys came from (two-level partition); 0 otherwise
+  // lane b owns the cursor of bucket b: address of its next group and the room left in its slice.  Kept in
+  // registers and read with v_readlane: no 64-bit multiply, no LDS word another lane could see stale.
+  uint64_t my_ptr;
+  uint32_t my_room;
 
-  // wave-major layout region[wave][bucket][slice_cap]: the 32 slices a wave writes to sit in ~1 MiB
+  // wave-major layout region[wave][bucket][slice_cap]: the slices a wave writes to sit within ~1 MiB
   __device__ __forceinline__ void init_cursors() {
     const uint32_t b = lane < (uint32_t)NB ? lane : 0u;
-    const uint64_t base = reinterpret_cast<uint64_t>(keys + ((size_t)wave_global * NB + b) * slice_cap);
-    my_base_lo = (uint32_t)base;
-    my_base_hi = (uint32_t)(base >> 32);
-    my_pos = 0;
+    my_ptr = reinterpret_cast<uint64_t>(keys + ((size_t)wave_global * NB + b) * slice_cap);
+    my_room = slice_cap;
   }
 
-  // write the 64 ring entries starting at ring index g0 to the slice (PARTIAL: entries >= nvalid become
-  // KEY_INVALID); b, g0, nvalid are wave-uniform.  Lanes 0..31 each move two entries (one dword): the group
-  // leaves as one 128-byte line of dword stores.
+  // Write the 64 ring entries starting at ring index g0 to the slice as ONE 128-byte line (one 2-byte store
+  // per lane; PARTIAL: entries >= nvalid become KEY_INVALID).  b, g0, nvalid are wave-uniform.  The body is
+  // kept short on purpose: it runs about once per window and every scalar instruction in it costs a full
+  // issue slot (the kernel is issue-bound, SALU included).
   template <bool PARTIAL>
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
-    const uint32_t pos = __builtin_amdgcn_readlane(my_pos, b);
-    constexpr uint32_t HALF = GROUP / 2;  // lanes that carry a dword
-    uint32_t v = __hip_atomic_load(&scatter_lds<NBITS>().ring[wave][b][((g0 >> 1) + (lane & (HALF - 1u))) & (RING_CAP / 2 - 1)],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    const uint32_t e0 = 2u * (lane & (HALF - 1u));
-    if (PARTIAL) {
-      if (e0 >= nvalid) v |= 0xFFFFu;  // KEY_INVALID in the low half
-      if (e0 + 1u >= nvalid) v |= 0xFFFF0000u;
-    }
-    if (pos + (uint32_t)GROUP <= slice_cap) {  // wave-uniform
+    const uint16_t* ring16 = reinterpret_cast<const uint16_t*>(&scatter_lds<NBITS>().ring[wave][b][0]);
+    uint32_t v = __hip_atomic_load(&ring16[(g0 + lane) & (RING_CAP - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (PARTIAL && lane >= nvalid) v = KEY_INVALID;
+    const uint32_t room = (uint32_t)__builtin_amdgcn_readlane((int)my_room, b);
+    if (room >= (uint32_t)GROUP) {  // wave-uniform
       // readlane returns int: widen through uint32_t or the low half sign-extends into the high one
-      const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_base_hi, b) << 32) |
-                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_base_lo, b);
-      // the pointer is rebuilt from integers: say "global" explicitly, or the store becomes flat_store (which
-      // also counts on lgkmcnt and stalls the next LDS wait for a full memory round trip)
-      typedef __attribute__((address_space(1))) uint32_t global_u32;
-      global_u32* dst = (global_u32*)(base + 2ull * pos);
-      if (lane < HALF && !(dbg & 1u)) dst[lane] = v;
-      if (lane == b) my_pos = pos + (uint32_t)GROUP;
-    } else if (lane < HALF) {  // slice full: count these windows directly (rare; keeps skewed inputs correct)
-      if (!PARTIAL || e0 < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v & 0xFFFFu, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!PARTIAL || e0 + 1u < nvalid) __hip_atomic_fetch_add(&hist[KS::join(b, v >> 16, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t ptr = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_ptr >> 32), b) << 32) |
+                           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_ptr, b);
+      ((global_u16*)ptr)[lane] = (uint16_t)v;  // explicit global address space: a flat store would stall LDS waits
+      const bool mine = lane == b;
+      my_ptr += mine ? 2ull * GROUP : 0ull;
+      my_room -= mine ? (uint32_t)GROUP : 0u;
+    } else if (!PARTIAL || lane < nvalid) {  // slice full: count these windows directly (rare; skewed inputs)
+      __hip_atomic_fetch_add(&hist[KS::join(b, v, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
-  __device__ __forceinline__ void operator()(uint32_t can, bool active) {
-    if (dbg & 4u) active = false;
-    const uint32_t b = active ? KS::bucket(can) : (uint32_t)NB;  // every lane appends; inactive ones to the sink
+  // The append is software-pipelined: a call first completes the PREVIOUS key (its ring slot has arrived
+  // meanwhile: ring write, group-complete check, flush) and then only ISSUES the LDS atomic for the current
+  // one, so the atomic's latency is covered by the scan arithmetic of the next window instead of an
+  // s_waitcnt right behind it.  (Deferring the flush by one more window was tried and bought nothing.)
+  uint32_t p_slot = 0, p_b = NB, p_payload = 0;
+  bool p_active = false;
+
+  __device__ __forceinline__ void finish_pending() {
     ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
-    const uint32_t slot = atomicAdd(&sh.fill[wave][b], 1u);
-    reinterpret_cast<uint16_t*>(&sh.ring[wave][b][0])[slot & (RING_CAP - 1)] = (uint16_t)KS::payload(can);
-    unsigned long long trig = __builtin_amdgcn_ballot_w64(active && (slot & (uint32_t)(GROUP - 1)) == (uint32_t)(GROUP - 1));
-    if (dbg & 2u) trig = 0;
+    reinterpret_cast<uint16_t*>(&sh.ring[wave][p_b][0])[p_slot & (RING_CAP - 1)] = (uint16_t)p_payload;
+    unsigned long long trig = __builtin_amdgcn_ballot_w64(p_active && (p_slot & (uint32_t)(GROUP - 1)) == (uint32_t)(GROUP - 1));
     while (trig) {  // wave-uniform: a ring just completed a group of 64
-      const int src = __ffsll((long long)trig) - 1;
+      const int src = __builtin_ctzll(trig);
       trig &= trig - 1;
-      const uint32_t fb = __builtin_amdgcn_readlane(b, src);
-      const uint32_t fs = __builtin_amdgcn_readlane(slot, src);
+      const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)p_b, src);
+      const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)p_slot, src);
       __builtin_amdgcn_wave_barrier();
       flush_group<false>(fb, fs - (uint32_t)(GROUP - 1), (uint32_t)GROUP);
     }
   }
 
+  __device__ __forceinline__ void operator()(uint32_t can, bool active) {
+    // keep the scheduler from hoisting the completion of the previous key above this window's scan
+    // arithmetic (it would put the s_waitcnt right behind the atomic again)
+    __builtin_amdgcn_sched_barrier(0);
+    finish_pending();  // (the first call completes a dummy append to the sink bucket)
+    p_b = active ? KS::bucket(can) : (uint32_t)NB;  // every lane appends; inactive ones to the sink
+    p_payload = KS::payload(can);
+    p_active = active;
+    p_slot = atomicAdd(&scatter_lds<NBITS>().fill[wave][p_b], 1u);
+  }
+
   // end of kernel: partial groups, then publish how much of each slice is filled
   __device__ __forceinline__ void drain() {
+    finish_pending();
+    p_active = false;
+    p_b = NB;
     __builtin_amdgcn_wave_barrier();
     for (uint32_t b = 0; b < (uint32_t)NB; ++b) {
       const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().fill[wave][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       const uint32_t r = f & (uint32_t)(GROUP - 1);
       if (r) flush_group<true>(b, f & ~(uint32_t)(GROUP - 1), r);
     }
-    if (lane < (uint32_t)NB) slice_fill[(size_t)wave_global * NB + lane] = my_pos;
+    if (lane < (uint32_t)NB) slice_fill[(size_t)wave_global * NB + lane] = slice_cap - my_room;
   }
 };
 
@@ -409,17 +418,17 @@ __global__ __launch_bounds__(256) void count_scatter_kernel(const uint32_t* __re
                                                             uint16_t* __restrict__ keys, uint32_t slice_cap,
                                                             uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
                                                             unsigned long long* __restrict__ ltot,
-                                                            uint32_t* __restrict__ defer, uint32_t dbg,
+                                                            uint32_t* __restrict__ defer,
                                                             uint32_t* __restrict__ bg_partials) {
   static_assert(2 * W - NBITS == PAYLOAD_BITS, "payload must be 15 bits");
   ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
   for (uint32_t i = threadIdx.x; i < 4u * ((1u << NBITS) + 1u); i += blockDim.x) (&sh.fill[0][0])[i] = 0;
   bg_begin<BG>();
   __syncthreads();
-  ScatterEmit<KeySplit<W, NBITS>, NBITS> e{keys, slice_cap, gridDim.x * 4u, slice_fill, hist, threadIdx.x >> 6,
-                                           threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6), 0u, 0u, 0u, dbg, 0u};
+  ScatterEmit<KeySplit<W, NBITS>, NBITS> e{keys, slice_cap, slice_fill, hist, threadIdx.x >> 6, threadIdx.x & 63u,
+                                           blockIdx.x * 4u + (threadIdx.x >> 6), 0u, 0ull, 0u};
   e.init_cursors();
-  scan_items<W, BOTH, BG>(words32, items, n_items, ltot, defer, e, dbg);
+  scan_items<W, BOTH, BG>(words32, items, n_items, ltot, defer, e);
   e.drain();
   bg_end<BG>(bg_partials);
 }
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
   __syncthreads();
   const uint32_t b1 = blockIdx.x / bpb1, j = blockIdx.x % bpb1;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  ScatterEmit<Split12L2, 4> e{keys2, cap2, gridDim.x * 4u, fill2, hist, wave, lane, blockIdx.x * 4u + wave, 0u, 0u, 0u, 0u, b1};
+  ScatterEmit<Split12L2, 4> e{keys2, cap2, fill2, hist, wave, lane, blockIdx.x * 4u + wave, b1, 0ull, 0u};
   e.init_cursors();
   const uint32_t per = (n_slices1 + bpb1 - 1) / bpb1;
   const uint32_t first = j * per, last = min(n_slices1, first + per);
@@ -955,7 +964,7 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   }
 #define TA_SCATTER(B, G) W, B, NBITS, G
   PENGK_LAUNCH_BB(count_scatter_kernel, TA_SCATTER, both, d_bg != nullptr, dim3(blocks), dim3(256), w32, ctx->d_items, n_items,
-                  keys, slice_cap, slice_fill, d_counts, lt, ctx->d_defer, (uint32_t)ctx->debug_flags, bgp);
+                  keys, slice_cap, slice_fill, d_counts, lt, ctx->d_defer, bgp);
 #undef TA_SCATTER
   PENGK_HIP(hipGetLastError());
   if (d_bg) {
