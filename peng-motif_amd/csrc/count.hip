@@ -15,10 +15,15 @@
 // front of its first window.  If no window of the prologue is suppressed, the ring it leaves is
 // provably the true one (see DESIGN.md "non-overlap rule"); otherwise the item is pushed on a
 // defer list and redone by count_fixup_kernel, which searches backwards for a certified start.
+#include <stdlib.h>
+
 #include "pengk_internal.h"
 
 #ifndef PENGK_RING_CAP
 #define PENGK_RING_CAP 128
+#endif
+#ifndef PENGK_ABLATE
+#define PENGK_ABLATE 0  // timing experiments (compile time): 1 = never flush, 2 = no append at all, 4 = no fused K1b
 #endif
 
 namespace pengk {
@@ -58,7 +63,7 @@ template <int W, bool BG>
 struct BgCount {
   uint32_t wave;
   __device__ __forceinline__ void kmer3(uint32_t id, bool on) const {
-    if (BG) atomicAdd(&bg_lds().bins[wave][on ? (id >> (2 * W - 6)) : 95u], 1u);  // bin 95 is a sink: no exec-mask dance
+    if (BG && !(PENGK_ABLATE & 4)) atomicAdd(&bg_lds().bins[wave][on ? (id >> (2 * W - 6)) : 95u], 1u);  // bin 95: sink
   }
   // base at run position sp (static) of a non-continuing item, id already rolled
   __device__ __forceinline__ void head(uint32_t id, int sp, bool on) const {
@@ -349,7 +354,7 @@ struct ScatterEmit {
   template <bool PARTIAL>
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
     const uint16_t* ring16 = reinterpret_cast<const uint16_t*>(&scatter_lds<NBITS>().ring[wave][b][0]);
-    uint32_t v = __hip_atomic_load(&ring16[(g0 + lane) & (RING_CAP - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    uint32_t v = __hip_atomic_load(&ring16[(g0 + 2u * b + lane) & (RING_CAP - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (PARTIAL && lane >= nvalid) v = KEY_INVALID;
     const uint32_t room = (uint32_t)__builtin_amdgcn_readlane((int)my_room, b);
     if (room >= (uint32_t)GROUP) {  // wave-uniform
@@ -374,8 +379,11 @@ struct ScatterEmit {
 
   __device__ __forceinline__ void finish_pending() {
     ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
-    reinterpret_cast<uint16_t*>(&sh.ring[wave][p_b][0])[p_slot & (RING_CAP - 1)] = (uint16_t)p_payload;
+    // ring position rotated by 2*bucket (= one bank per bucket): all rings fill at the same pace, and with a
+    // row stride of 256 B equal fill levels would put every lane of the ds_write on the same few banks
+    reinterpret_cast<uint16_t*>(&sh.ring[wave][p_b][0])[(p_slot + 2u * p_b) & (RING_CAP - 1)] = (uint16_t)p_payload;
     unsigned long long trig = __builtin_amdgcn_ballot_w64(p_active && (p_slot & (uint32_t)(GROUP - 1)) == (uint32_t)(GROUP - 1));
+    if (PENGK_ABLATE & 1) trig = 0;
     while (trig) {  // wave-uniform: a ring just completed a group of 64
       const int src = __builtin_ctzll(trig);
       trig &= trig - 1;
@@ -390,6 +398,7 @@ struct ScatterEmit {
     // keep the scheduler from hoisting the completion of the previous key above this window's scan
     // arithmetic (it would put the s_waitcnt right behind the atomic again)
     __builtin_amdgcn_sched_barrier(0);
+    if (PENGK_ABLATE & 2) return;
     finish_pending();  // (the first call completes a dummy append to the sink bucket)
     p_b = active ? KS::bucket(can) : (uint32_t)NB;  // every lane appends; inactive ones to the sink
     p_payload = KS::payload(can);
@@ -935,7 +944,9 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
   // grid of pass A: LDS (33 KiB per block at NB = 32) admits 4 blocks per CU
   const uint32_t blocks_needed = (n_items + 255) / 256;
-  const uint32_t max_blocks = (uint32_t)ctx->num_cu * (RING_CAP >= 128 ? 4u : 8u);
+  uint32_t per_cu = RING_CAP >= 128 ? 4u : 8u;
+  if (const char* e = getenv("PENGK_SCATTER_BLOCKS_PER_CU")) per_cu = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : per_cu;  // experiments
+  const uint32_t max_blocks = (uint32_t)ctx->num_cu * per_cu;
   const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
   const uint32_t n_waves = blocks * 4u;
   // static slices region[wave][bucket]: expected share + 50 % + slack, in groups of 64 entries
