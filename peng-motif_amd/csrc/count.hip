@@ -23,7 +23,8 @@
 #define PENGK_RING_CAP 128
 #endif
 #ifndef PENGK_ABLATE
-#define PENGK_ABLATE 0  // timing experiments (compile time): 1 = never flush, 2 = no append at all, 4 = no fused K1b
+#define PENGK_ABLATE 0  // timing experiments (compile time): 1 = never flush, 2 = no append at all, 4 = no fused K1b,
+                        // 8 = conflict-free bucket per lane (wrong results)
 #endif
 
 namespace pengk {
@@ -354,14 +355,16 @@ struct ScatterEmit {
   template <bool PARTIAL>
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
     const uint16_t* ring16 = reinterpret_cast<const uint16_t*>(&scatter_lds<NBITS>().ring[wave][b][0]);
-    uint32_t v = __hip_atomic_load(&ring16[(g0 + 2u * b + lane) & (RING_CAP - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    uint32_t v = (PENGK_ABLATE & 16) ? lane  // experiment: no LDS read in the flush
+                                     : __hip_atomic_load(&ring16[(g0 + 2u * b + lane) & (RING_CAP - 1)], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (PARTIAL && lane >= nvalid) v = KEY_INVALID;
     const uint32_t room = (uint32_t)__builtin_amdgcn_readlane((int)my_room, b);
     if (room >= (uint32_t)GROUP) {  // wave-uniform
       // readlane returns int: widen through uint32_t or the low half sign-extends into the high one
       const uint64_t ptr = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_ptr >> 32), b) << 32) |
                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_ptr, b);
-      ((global_u16*)ptr)[lane] = (uint16_t)v;  // explicit global address space: a flat store would stall LDS waits
+      if (!(PENGK_ABLATE & 32)) ((global_u16*)ptr)[lane] = (uint16_t)v;  // explicit global address space (a flat store would stall LDS waits)
       const bool mine = lane == b;
       my_ptr += mine ? 2ull * GROUP : 0ull;
       my_room -= mine ? (uint32_t)GROUP : 0u;
@@ -401,6 +404,7 @@ struct ScatterEmit {
     if (PENGK_ABLATE & 2) return;
     finish_pending();  // (the first call completes a dummy append to the sink bucket)
     p_b = active ? KS::bucket(can) : (uint32_t)NB;  // every lane appends; inactive ones to the sink
+    if (PENGK_ABLATE & 8) p_b = lane & (uint32_t)(NB - 1);  // experiment: conflict-free counter addresses
     p_payload = KS::payload(can);
     p_active = active;
     p_slot = atomicAdd(&scatter_lds<NBITS>().fill[wave][p_b], 1u);
