@@ -71,7 +71,7 @@ void* pengk_stream(pengk_ctx* ctx);
 int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
 
 /* Tunables / introspection.  Options: "count_impl" 0 = auto, 1 = direct global atomics, 2 = partitioned LDS
- * histograms (W = 8, 10); "n_windows_hint" = total windows of the attached items (sizes the key buffer
+ * histograms (W = 8, 10, 12); "n_windows_hint" = total windows of the attached items (sizes the key buffer
  * tightly; set it after pengk_set_sequences); "key_cap_override" (test hook) entries per bucket region of the
  * partitioned count, 0 = automatic.  Info: "deferred_items" (of the last pengk_count;
  * synchronises), "num_cu". */

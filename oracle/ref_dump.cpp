@@ -5,7 +5,7 @@
 // TEST INFRASTRUCTURE ONLY.  It exists to (a) pin oracle/peng_oracle.cpp and (b) produce the
 // golden vectors committed under tests/golden/ (see tests/golden/make_golden.py).
 //
-// usage: ref_dump <fasta> <W> <BOTH|PLUS> <outdir>
+// usage: ref_dump <fasta> <W> <BOTH|PLUS> <outdir> [tables]
 // writes raw little-endian arrays + text tables into <outdir>.
 
 #include <algorithm>
@@ -55,6 +55,7 @@ int main(int argc, char** argv) {
   const int W = atoi(argv[2]);
   const Strand strand = strcmp(argv[3], "PLUS") == 0 ? Strand::PLUS_STRAND : Strand::BOTH_STRANDS;
   const std::string out = argv[4];
+  const bool tables_only = argc > 5 && strcmp(argv[5], "tables") == 0;  // skip the IUPAC / EM stages (large inputs)
 
   Alphabet::init("STANDARD");
   SequenceSet* ss = new SequenceSet(fasta, true);
@@ -116,6 +117,7 @@ int main(int argc, char** argv) {
     fclose(f);
   }
 
+  if (tables_only) return 0;
   // ---- IUPAC aggregation: every seed (first 12) and all of its single-letter mutants, plus a
   //      second generation from the first mutant of each position (more degenerate letters) -----
   {

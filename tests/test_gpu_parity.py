@@ -320,6 +320,38 @@ def test_fused_bg_count_with_deferred_items(ctx):
     assert np.array_equal(bg.to_host().astype(np.int64), po.bg_counts(codes, offs, 2))
 
 
+def _synth_cases():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth_checksums.json")
+    return json.load(open(path))
+
+
+@pytest.mark.parametrize("case", _synth_cases(), ids=lambda c: "W%d_%s_%d" % (c["W"], c["strand"], c["n_seq"]))
+def test_device_generated_input_against_reference_checksums(ctx, case):
+    """Sequences generated ON THE DEVICE (pengk_synth_sequences) -> fused count -> bg model -> sweep, compared
+    with sha256 checksums of the compiled reference's tables for the same synthetic set
+    (tests/golden/make_synth_golden.py): tens of Mbp at W = 10 and W = 12, beyond the per-element fixtures."""
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    W, both = case["W"], case["strand"] == "BOTH"
+    ctx.synth(case["seed"], case["seq0"], case["n_seq"], case["L"], W)
+    counts, ltot, bg = ctx.count_bg(both)
+    if both:
+        ctx.mirror(W, counts)
+    assert int(ltot.to_host()[0]) == case["ltot"]
+    assert bg.to_host().astype(np.int64).tolist() == case["bgcounts"]
+    assert sha(counts.to_host()) == case["sha_counts_u32"]
+    V = ctx.bg_model(bg, 2)
+    assert sha(V.to_host()) == case["sha_V"]
+    bgprob, expected, logp, z = ctx.pattern_stats(W, both, 2, 2, V, ltot, counts)
+    assert sha(bgprob.to_host()[2]) == case["sha_bgp2"]
+    assert sha(expected.to_host()) == case["sha_expected"]
+    zz = z.to_host()
+    assert sha(zz) == case["sha_z"]
+    seeds = po.select(W, zz, counts.to_host().astype(np.uint64), 10.0, 3, not both, True)
+    assert seeds[:40].tolist() == case["seeds"]
+
+
 def test_synthetic_generator_matches_cpu(ctx):
     """pengk_synth_sequences == the counter-based generator of SURVEY.md 8d (oracle po_synth)."""
     n, L, W = 3000, 200, 10
