@@ -277,10 +277,40 @@ def cpu_baseline(args, W, both, L):
     for _ in range(npw):
         po.em(W, counts, bgp[2], pw, 1e4, 0.0, 10, mode=0)
     t_em = time.perf_counter() - t0
-    return {"value": round(n * L / t_count / 1e9, 5), "unit": "Gbp/s", "cores": 1, "kind": "port",
+    extra = reference_probe(W, both, L)
+    return {"value": round(n * L / t_count / 1e9, 5), "unit": "Gbp/s", "cores": 1, "kind": "port", **extra,
             "sample": "oracle (bit-exact port of the reference's serial loops, g++ -O3, 1 thread) on %d x %d bp of the same synthetic set: count %.2f s; %d sweeps over 4^%d patterns %.3f s each; %d PWMs x 10 EM iterations %.2f s"
                       % (n, L, t_count, nsweep, W, t_sweep, npw, t_em),
             "zscores_per_s": round(4 ** W / t_sweep, 1), "em_evals_per_s": round(npw * 10 * 4 ** W / t_em, 1)}
+
+
+def reference_probe(W, both, L, n=400_000):
+    """When the build of the real reference travelled with the repository (oracle/_ref/ref_dump, built in the
+    build container from /root/reference), time ITS BasePattern constructor (background probabilities + count +
+    expected / log-p / z: src/base_pattern.cpp:17-64) on a sample of the same synthetic set, on this host.
+    Reported beside the port so that the port can be seen not to flatter the GPU."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    if not os.path.exists(exe):
+        return {}
+    import subprocess
+    import tempfile
+    from oracle import oracle as po
+    try:
+        tmp = tempfile.mkdtemp(prefix="pengk_refprobe_")
+        codes, _ = po.synth(1, 0, n, L)
+        rows = np.frombuffer(b"NACGT", dtype=np.uint8)[codes].reshape(n, L)
+        with open(os.path.join(tmp, "s.fa"), "wb") as f:
+            f.write(b"".join((">s%d\n" % i).encode() + rows[i].tobytes() + b"\n" for i in range(n)))
+        subprocess.run([exe, os.path.join(tmp, "s.fa"), str(W), "BOTH" if both else "PLUS", tmp, "tables"], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        meta = dict(l.split() for l in open(os.path.join(tmp, "meta.txt")))
+        t = float(meta["basepattern_seconds"])
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+        return {"reference_basepattern_gbp_per_s": round(n * L / t / 1e9, 5),
+                "reference_sample": "compiled reference (oracle/_ref, g++ -O3, 1 thread): BasePattern constructor on %d x %d bp in %.2f s" % (n, L, t)}
+    except Exception as e:  # the probe is optional
+        return {"reference_sample": "probe failed: %r" % (e,)}
 
 
 if __name__ == "__main__":

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -91,7 +92,9 @@ int main(int argc, char** argv) {
 
   // ---- BasePattern tables -----------------------------------------------------------------------
   IUPACPattern::init(17, bg->getV()[0]);
+  const auto t_bp0 = std::chrono::steady_clock::now();
   BasePattern* bp = new BasePattern(W, strand, K, K, ss, bg);
+  const double t_bp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_bp0).count();
   const size_t NP = bp->getNumberPatterns();
   {
     std::vector<uint64_t> c(NP);
@@ -112,8 +115,8 @@ int main(int argc, char** argv) {
   }
   {
     FILE* f = fopen((out + "/meta.txt").c_str(), "w");
-    fprintf(f, "W %d\nNP %zu\nltot %zu\nN %zu\nK %d\nstrand %s\nnseeds %zu\n", W, NP, bp->getLtot(), ss->getN(), K,
-            strand == Strand::PLUS_STRAND ? "PLUS" : "BOTH", seeds.size());
+    fprintf(f, "W %d\nNP %zu\nltot %zu\nN %zu\nK %d\nstrand %s\nnseeds %zu\nbasepattern_seconds %.6f\n", W, NP, bp->getLtot(),
+            ss->getN(), K, strand == Strand::PLUS_STRAND ? "PLUS" : "BOTH", seeds.size(), t_bp);
     fclose(f);
   }
 
