@@ -73,7 +73,8 @@ int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
 /* Tunables / introspection.  Options: "count_impl" 0 = auto, 1 = direct global atomics, 2 = partitioned LDS
  * histograms (W = 8, 10, 12); "n_windows_hint" = total windows of the attached items (sizes the key buffer
  * tightly; set it after pengk_set_sequences); "key_cap_override" (test hook) entries per bucket region of the
- * partitioned count, 0 = automatic.  Info: "deferred_items" (of the last pengk_count;
+ * partitioned count, 0 = automatic; "iupac_group_bytes" (test hook) scratch budget for one group of large
+ * patterns in pengk_iupac_aggregate, 0 = 1 GiB.  Info: "deferred_items" (of the last pengk_count;
  * synchronises), "num_cu". */
 int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value);
 int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value_out);
@@ -83,6 +84,11 @@ int pengk_free(pengk_ctx* ctx, void* d_ptr);
 int pengk_memcpy_h2d(pengk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* synchronous */
 int pengk_memcpy_d2h(pengk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous */
 int pengk_memset(pengk_ctx* ctx, void* d_dst, int byte, size_t bytes);              /* async */
+/* Page-locked host memory for result tables: the reference's BasePattern hands out raw host arrays
+ * (src/base_pattern.h:129-140: size_t counts, float probabilities / expected / z / log-p, 4^W each); mirrors of
+ * the device tables land in them at link speed when they are allocated here.  Ordinary host pointers otherwise. */
+int pengk_host_alloc(pengk_ctx* ctx, size_t bytes, void** h_out);
+int pengk_host_free(pengk_ctx* ctx, void* h_ptr);
 
 /* Stream-ordered event timing without exposing HIP types: records an event on the context's stream;
  * pengk_timer_elapsed_ms synchronises on `stop`. */

@@ -116,6 +116,10 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     ctx->key_cap_override = (uint64_t)value;
     return PENGK_OK;
   }
+  if (strcmp(name, "iupac_group_bytes") == 0) {
+    ctx->iupac_group_bytes = (uint64_t)value;
+    return PENGK_OK;
+  }
   if (strcmp(name, "n_windows_hint") == 0) {
     ctx->n_windows_hint = (uint64_t)value;
     return PENGK_OK;
@@ -165,6 +169,23 @@ int pengk_free(pengk_ctx* ctx, void* d_ptr) {
   if (d_ptr) {
     PENGK_HIP(hipStreamSynchronize(ctx->stream));
     PENGK_HIP(hipFree(d_ptr));
+  }
+  return PENGK_OK;
+}
+
+int pengk_host_alloc(pengk_ctx* ctx, size_t bytes, void** h_out) {
+  if (!ctx || !h_out) return fail(PENGK_ERR_ARG, "pengk_host_alloc: NULL argument");
+  PENGK_HIP(hipSetDevice(ctx->device));
+  hipError_t e = hipHostMalloc(h_out, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(PENGK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  return PENGK_OK;
+}
+
+int pengk_host_free(pengk_ctx* ctx, void* h_ptr) {
+  if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  if (h_ptr) {
+    PENGK_HIP(hipStreamSynchronize(ctx->stream));
+    PENGK_HIP(hipHostFree(h_ptr));
   }
   return PENGK_OK;
 }

@@ -19,8 +19,10 @@
 // :446-470) are finished in launch_iupac with the same libm the reference links.
 #include <math.h>
 
+#include <algorithm>
 #include <limits>
 #include <new>
+#include <vector>
 
 #include "pengk_internal.h"
 
@@ -195,7 +197,24 @@ __device__ __forceinline__ uint32_t spec_member(const PatternSpec& ps, uint32_t 
   return x;
 }
 
-__global__ __launch_bounds__(256) void iupac_mark_kernel(PatternSpec ps, uint32_t* __restrict__ bitmap) {
+// One "slot" per large pattern of a group; blockIdx.y selects the slot, so all large patterns of a group run side
+// by side (the fold is one wave per pattern: 50 N-rich mutants of a hill-climb round fold on 50 CUs at once
+// instead of one after the other).  Slot y owns bitmap[y * n_words ..), lists [y * cap ..), head[y].
+struct BigSlot {
+  PatternSpec ps;
+  uint32_t out_index;  // row of the output this pattern belongs to
+  uint32_t pad;
+};
+struct BigHead {  // zeroed before every group
+  uint32_t m;     // BOTH: number of distinct canonical ids
+  uint32_t pad;
+  unsigned long long cnt;
+};
+
+__global__ __launch_bounds__(256) void iupac_mark_kernel(const BigSlot* __restrict__ slots, uint32_t* __restrict__ bitmaps,
+                                                         uint32_t n_words) {
+  const PatternSpec ps = slots[blockIdx.y].ps;
+  uint32_t* bitmap = bitmaps + (size_t)blockIdx.y * n_words;
   const uint32_t n = 1u << ps.lgn;
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
     const uint32_t x = spec_member(ps, k);
@@ -205,12 +224,14 @@ __global__ __launch_bounds__(256) void iupac_mark_kernel(PatternSpec ps, uint32_
   }
 }
 
-// one workgroup: ascending ids of the set bits -> out_ids, their number -> *out_m
-__global__ __launch_bounds__(1024) void iupac_compact_kernel(const uint32_t* __restrict__ bitmap, uint32_t n_words,
-                                                             uint32_t* __restrict__ out_ids, uint32_t* __restrict__ out_m) {
+// one workgroup per slot: ascending ids of the set bits -> the slot's id list, their number -> head.m
+__global__ __launch_bounds__(1024) void iupac_compact_kernel(const uint32_t* __restrict__ bitmaps, uint32_t n_words,
+                                                             uint32_t* __restrict__ lists, size_t cap, BigHead* __restrict__ heads) {
   __shared__ uint32_t s_scan[1024];
+  const uint32_t* bitmap = bitmaps + (size_t)blockIdx.y * n_words;
+  uint32_t* out_ids = lists + (size_t)blockIdx.y * cap;
   const uint32_t per = (n_words + 1023u) / 1024u;
-  const uint32_t w0 = threadIdx.x * per, w1 = min(n_words, w0 + per);
+  const uint32_t w0 = min(n_words, threadIdx.x * per), w1 = min(n_words, w0 + per);
   uint32_t mine = 0;
   for (uint32_t w = w0; w < w1; ++w) mine += __popc(bitmap[w]);
   s_scan[threadIdx.x] = mine;
@@ -230,33 +251,40 @@ __global__ __launch_bounds__(1024) void iupac_compact_kernel(const uint32_t* __r
       out_ids[at++] = (w << 5) | b;
     }
   }
-  if (threadIdx.x == 1023) *out_m = s_scan[1023];
+  if (threadIdx.x == 1023) heads[blockIdx.y].m = s_scan[1023];
 }
 
-// values in list order; ids == nullptr: list = emission order of `ps` (PLUS), m = 2^lgn
-__global__ __launch_bounds__(256) void iupac_gather_kernel(PatternSpec ps, const uint32_t* __restrict__ ids,
-                                                           const uint32_t* __restrict__ m_ptr,
+// values in list order; use_list == 0: list = emission order of the pattern (PLUS), m = 2^lgn
+__global__ __launch_bounds__(256) void iupac_gather_kernel(const BigSlot* __restrict__ slots, int use_list,
+                                                           const uint32_t* __restrict__ lists, size_t cap,
                                                            const uint32_t* __restrict__ counts, const float* __restrict__ bgp,
-                                                           const float* __restrict__ expected, float* __restrict__ vb,
-                                                           float* __restrict__ ve, unsigned long long* __restrict__ cnt_out) {
-  const uint32_t m = ids ? *m_ptr : (1u << ps.lgn);
+                                                           const float* __restrict__ expected, float* __restrict__ vbs,
+                                                           float* __restrict__ ves, BigHead* __restrict__ heads) {
+  const PatternSpec ps = slots[blockIdx.y].ps;
+  const uint32_t* ids = lists + (size_t)blockIdx.y * cap;
+  float* vb = vbs + (size_t)blockIdx.y * cap;
+  float* ve = ves + (size_t)blockIdx.y * cap;
+  const uint32_t m = use_list ? heads[blockIdx.y].m : (1u << ps.lgn);
   unsigned long long mine = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-    const uint32_t x = ids ? ids[i] : spec_member(ps, i);
+    const uint32_t x = use_list ? ids[i] : spec_member(ps, i);
     vb[i] = bgp[x];
     ve[i] = expected[x];
     mine += counts[x];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(cnt_out, mine);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&heads[blockIdx.y].cnt, mine);
 }
 
-// one wave: strictly sequential float32 sums of vb[0..m) and ve[0..m)
-__global__ __launch_bounds__(64) void iupac_fold_kernel(const float* __restrict__ vb, const float* __restrict__ ve,
-                                                        const uint32_t* __restrict__ m_ptr, uint32_t m_fixed,
-                                                        const unsigned long long* __restrict__ cnt, RawSums* __restrict__ out) {
-  const uint32_t m = m_ptr ? *m_ptr : m_fixed;
+// one wave per slot: strictly sequential float32 sums of the slot's vb[0..m) and ve[0..m)
+__global__ __launch_bounds__(64) void iupac_fold_kernel(const BigSlot* __restrict__ slots, int use_list, const float* __restrict__ vbs,
+                                                        const float* __restrict__ ves, size_t cap,
+                                                        const BigHead* __restrict__ heads, RawSums* __restrict__ out) {
+  const BigSlot slot = slots[blockIdx.x];
+  const float* vb = vbs + (size_t)blockIdx.x * cap;
+  const float* ve = ves + (size_t)blockIdx.x * cap;
+  const uint32_t m = use_list ? heads[blockIdx.x].m : (1u << slot.ps.lgn);
   const uint32_t lane = threadIdx.x;
   float sb = 0.0f, se = 0.0f;
   float nb = lane < m ? vb[lane] : 0.0f, ne = lane < m ? ve[lane] : 0.0f;
@@ -269,9 +297,10 @@ __global__ __launch_bounds__(64) void iupac_fold_kernel(const float* __restrict_
     se = chain_add(se, ce);
   }
   if (lane == 0) {
-    out->sites = *cnt;
-    out->bg_p = sb;
-    out->expected = se;
+    RawSums* o = out + slot.out_index;
+    o->sites = heads[blockIdx.x].cnt;
+    o->bg_p = sb;
+    o->expected = se;
   }
 }
 
@@ -299,8 +328,9 @@ int launch_iupac(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids, int64_t
   hipLaunchKernelGGL(iupac_block_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, W, both, d_ids, (int)n, d_counts, d_bgp,
                      d_expected, d_out);
   PENGK_HIP(hipGetLastError());
-  // large patterns: the data-parallel list pipeline, one pattern after the other
+  // large patterns: the data-parallel list pipeline, a group of patterns per round of launches
   static const int rep_n[11] = {1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 4};
+  std::vector<BigSlot> big;
   for (int64_t i = 0; i < n; ++i) {
     PatternSpec ps{0ull, W, 0};
     uint64_t t = h_ids[i];
@@ -310,35 +340,53 @@ int launch_iupac(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids, int64_t
       ps.letters4 |= (unsigned long long)L << (4 * p);
       ps.lgn += rep_n[L] == 1 ? 0 : (rep_n[L] == 2 ? 1 : 2);
     }
-    if ((1ull << ps.lgn) <= (unsigned long long)IUPAC_LDS_MAX) continue;
-    const uint32_t nmem = 1u << ps.lgn;
-    const uint32_t n_words = 1u << (2 * W - 5);
-    // scratch: bitmap | m | cnt | ids | vb | ve
-    const size_t bm_bytes = (size_t)n_words * 4, list_bytes = (size_t)nmem * 4;
-    rc = ensure_scratch(ctx, &ctx->d_iupac_big, &ctx->iupac_big_bytes, bm_bytes + 256 + 3 * list_bytes);
-    if (rc) return rc;
-    uint32_t* bitmap = (uint32_t*)ctx->d_iupac_big;
-    uint32_t* d_m = (uint32_t*)((char*)ctx->d_iupac_big + bm_bytes);
-    unsigned long long* d_cnt = (unsigned long long*)((char*)d_m + 64);
-    uint32_t* lst = (uint32_t*)((char*)ctx->d_iupac_big + bm_bytes + 256);
-    float* vb = (float*)(lst + nmem);
-    float* ve = vb + nmem;
-    PENGK_HIP(hipMemsetAsync(d_m, 0, 256, ctx->stream));
-    const unsigned gblocks = nmem / 256 < 2048u ? nmem / 256 : 2048u;
-    if (both) {
-      PENGK_HIP(hipMemsetAsync(bitmap, 0, bm_bytes, ctx->stream));
-      hipLaunchKernelGGL(iupac_mark_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, ps, bitmap);
-      hipLaunchKernelGGL(iupac_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, bitmap, n_words, lst, d_m);
-      hipLaunchKernelGGL(iupac_gather_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, ps, lst, d_m, d_counts, d_bgp, d_expected, vb,
-                         ve, d_cnt);
-      hipLaunchKernelGGL(iupac_fold_kernel, dim3(1), dim3(64), 0, ctx->stream, vb, ve, d_m, 0u, d_cnt, d_out + i);
-    } else {
-      hipLaunchKernelGGL(iupac_gather_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, ps, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, d_counts, d_bgp, d_expected, vb, ve, d_cnt);
-      hipLaunchKernelGGL(iupac_fold_kernel, dim3(1), dim3(64), 0, ctx->stream, vb, ve, (const uint32_t*)nullptr, nmem, d_cnt,
-                         d_out + i);
+    if ((1ull << ps.lgn) > (unsigned long long)IUPAC_LDS_MAX) big.push_back(BigSlot{ps, (uint32_t)i, 0u});
+  }
+  const uint32_t n_words = 1u << (2 * W - 5);
+  const size_t bm_bytes = both ? (size_t)n_words * 4 : 0;
+  const size_t budget = ctx->iupac_group_bytes ? (size_t)ctx->iupac_group_bytes : (size_t)1 << 30;  // scratch for one group
+  for (size_t g0 = 0; g0 < big.size();) {
+    // longest run of patterns whose slots (all sized for the largest member list among them) fit the budget
+    size_t g1 = g0, cap = 0;
+    while (g1 < big.size()) {
+      const size_t c = std::max(cap, (size_t)1 << big[g1].ps.lgn);
+      const size_t per_slot = bm_bytes + sizeof(BigSlot) + sizeof(BigHead) + 3 * c * 4;
+      if (g1 > g0 && ((g1 - g0 + 1) * per_slot > budget || g1 - g0 >= 65535)) break;
+      cap = c;
+      ++g1;
     }
+    const size_t G = g1 - g0;
+    // scratch: slots | heads | bitmaps | id lists | vb | ve   (every part 256-byte aligned)
+    auto pad256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_heads = pad256(G * sizeof(BigSlot));
+    const size_t o_bm = o_heads + pad256(G * sizeof(BigHead));
+    const size_t o_lst = o_bm + pad256(G * bm_bytes);
+    const size_t o_vb = o_lst + pad256(G * cap * 4);
+    const size_t o_ve = o_vb + pad256(G * cap * 4);
+    rc = ensure_scratch(ctx, &ctx->d_iupac_big, &ctx->iupac_big_bytes, o_ve + pad256(G * cap * 4));
+    if (rc) return rc;
+    char* base = (char*)ctx->d_iupac_big;
+    BigSlot* d_slots = (BigSlot*)base;
+    BigHead* d_heads = (BigHead*)(base + o_heads);
+    uint32_t* bitmaps = (uint32_t*)(base + o_bm);
+    uint32_t* lists = (uint32_t*)(base + o_lst);
+    float* vbs = (float*)(base + o_vb);
+    float* ves = (float*)(base + o_ve);
+    // the slot table is read by kernels of THIS group only after the copy; the previous group's kernels are ahead of it in
+    // the stream, and `big` outlives the synchronisation at the end of this function
+    PENGK_HIP(hipMemcpyAsync(d_slots, big.data() + g0, G * sizeof(BigSlot), hipMemcpyHostToDevice, ctx->stream));
+    PENGK_HIP(hipMemsetAsync(d_heads, 0, G * sizeof(BigHead), ctx->stream));
+    const unsigned gblocks = (unsigned)std::min<size_t>(std::max<size_t>(cap / 256, 1), 2048);
+    if (both) {
+      PENGK_HIP(hipMemsetAsync(bitmaps, 0, G * bm_bytes, ctx->stream));
+      hipLaunchKernelGGL(iupac_mark_kernel, dim3(gblocks, (unsigned)G), dim3(256), 0, ctx->stream, d_slots, bitmaps, n_words);
+      hipLaunchKernelGGL(iupac_compact_kernel, dim3(1, (unsigned)G), dim3(1024), 0, ctx->stream, bitmaps, n_words, lists, cap, d_heads);
+    }
+    hipLaunchKernelGGL(iupac_gather_kernel, dim3(gblocks, (unsigned)G), dim3(256), 0, ctx->stream, d_slots, both, lists, cap, d_counts,
+                       d_bgp, d_expected, vbs, ves, d_heads);
+    hipLaunchKernelGGL(iupac_fold_kernel, dim3((unsigned)G), dim3(64), 0, ctx->stream, d_slots, both, vbs, ves, cap, d_heads, d_out);
     PENGK_HIP(hipGetLastError());
+    g0 = g1;
   }
   RawSums* raw = new (std::nothrow) RawSums[(size_t)n];
   if (!raw) return fail(PENGK_ERR_NOMEM, "pengk_iupac_aggregate: out of host memory");

@@ -119,6 +119,197 @@ void write_range(const uint8_t* codes, const int64_t* offs, int64_t s0, int64_t 
   flush(g >> 5);
 }
 
+// ---- fast path: every sequence is one whole visited run (no invalid base, L >= W) ----------------------------
+// Then the stream is the 2-bit image of the contiguous code bytes and a sequence's stream position is known
+// without a prefix sum, so ONE pass does validity check, packing and the background counters, 8 bases per step.
+// Any other sequence makes the range report failure and pengk_pack restarts on the general two-pass path.
+inline uint64_t load8(const uint8_t* p) {
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v;
+}
+// 8 code bytes (1..4, first base in the low byte) -> nonzero iff one of them is not a valid code
+inline uint64_t invalid8(uint64_t v) {
+  const uint64_t zero = (v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull;          // a byte == 0
+  const uint64_t big = ((v + 0x7B7B7B7B7B7B7B7Bull) | v) & 0x8080808080808080ull;          // a byte >= 5
+  return zero | big;  // exact when all bytes are valid; any invalid byte gives nonzero (carries only add flags)
+}
+// 8 valid code bytes -> 16 bits, base j in bits [2j, 2j+2)
+inline uint32_t pack8(uint64_t v) {
+  uint64_t t = v - 0x0101010101010101ull;                 // digits 0..3 per byte
+  t = (t | (t >> 6)) & 0x000F000F000F000Full;             // 2 digits per 16-bit lane
+  t = (t | (t >> 12)) & 0x000000FF000000FFull;            // 4 digits per 32-bit lane
+  return (uint32_t)((t | (t >> 24)) & 0xFFFFu);
+}
+
+struct FastStat {
+  uint64_t windows = 0, items = 0, bound = 0, max_len = 0;
+  uint64_t h3[64] = {0};  // 3-mers ending at i >= 2, index = first base in the LOW digit
+  uint64_t e1[16] = {0};  // the 2-mer ending at i == 1 of every sequence (BaMM index: first base high)
+  uint64_t e0[4] = {0};   // the base at i == 0
+  int ok = 1;
+};
+
+void fast_range(const uint8_t* codes, const int64_t* offs, int64_t s0, int64_t s1, int W, uint64_t M, uint64_t g0, uint64_t* words,
+                FastStat& st) {
+  uint64_t g = g0;    // stream position of the next base
+  uint64_t acc = 0;   // bits gathered for word g >> 5
+  bool shared = true; // the first and the last word of the range may be shared with a neighbour range
+  auto put = [&](uint64_t word) {
+    if (shared) {
+      if (acc) __atomic_fetch_or(&words[word], acc, __ATOMIC_RELAXED);
+      shared = false;
+    } else {
+      words[word] = acc;
+    }
+    acc = 0;
+  };
+  for (int64_t s = s0; s < s1; ++s) {
+    const uint8_t* seq = codes + offs[s];
+    const int64_t L = offs[s + 1] - offs[s];
+    if (L < W) {
+      st.ok = 0;
+      return;
+    }
+    if ((uint64_t)L > st.max_len) st.max_len = (uint64_t)L;
+    uint64_t bad = 0;
+    uint32_t carry = 0;  // the last two bases seen (4 bits)
+    int64_t i = 0;
+    for (; i + 8 <= L; i += 8) {
+      const uint64_t v = load8(seq + i);
+      bad |= invalid8(v);
+      const uint32_t t = pack8(v);
+      const unsigned sh = 2u * (unsigned)(g & 31);
+      acc |= (uint64_t)t << sh;
+      g += 8;
+      if (sh + 16 >= 64) {
+        put((g >> 5) - 1);
+        if (sh + 16 > 64) acc = (uint64_t)t >> (64 - sh);
+      }
+      const uint32_t x = carry | (t << 4);  // base j of the chunk sits at bits [2j+4, 2j+6)
+      if (i) {
+        ++st.h3[x & 63];
+        ++st.h3[(x >> 2) & 63];
+      }
+      ++st.h3[(x >> 4) & 63];
+      ++st.h3[(x >> 6) & 63];
+      ++st.h3[(x >> 8) & 63];
+      ++st.h3[(x >> 10) & 63];
+      ++st.h3[(x >> 12) & 63];
+      ++st.h3[(x >> 14) & 63];
+      carry = t >> 12;
+    }
+    for (; i < L; ++i) {
+      const unsigned c = seq[i];
+      bad |= (c == 0 || c > 4);
+      const uint32_t d = (c - 1u) & 3u;
+      acc |= (uint64_t)d << (2 * (g & 31));
+      ++g;
+      if ((g & 31) == 0) put((g >> 5) - 1);
+      if (i >= 2) ++st.h3[carry | (d << 4)];
+      carry = (carry >> 2) | (d << 2);
+    }
+    if (bad) {
+      st.ok = 0;
+      return;
+    }
+    // the two incomplete k-mers at the head of the sequence (L >= W >= 4)
+    const unsigned b0 = seq[0] - 1u, b1 = seq[1] - 1u;
+    ++st.e0[b0];
+    ++st.e1[b0 * 4 + b1];
+    const uint64_t nwin = (uint64_t)(L - W + 1);
+    st.windows += nwin;
+    st.bound += (nwin + W - 1) / W;
+    st.items += (nwin + M - 1) / M;
+  }
+  shared = true;
+  put(g >> 5);
+}
+
+void fast_items(const int64_t* offs, int64_t s0, int64_t s1, int W, uint64_t M, uint64_t item0, uint64_t* items) {
+  uint64_t it = item0;
+  for (int64_t s = s0; s < s1; ++s) {
+    const uint64_t run0 = PENGK_FRONT_PAD_BASES + (uint64_t)(offs[s] - offs[0]);
+    const uint64_t nwin = (uint64_t)(offs[s + 1] - offs[s] - W + 1);
+    for (uint64_t f = 0; f < nwin; f += M) {
+      const uint64_t nw = nwin - f < M ? nwin - f : M;
+      items[it++] = (run0 + f) | (nw << ITEM_NW_SHIFT) | ((uint64_t)(f ? 1 : 0) << ITEM_CONT_SHIFT);
+    }
+  }
+}
+
+template <class F>
+void run_ranges(unsigned nt, F&& f) {
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(f, t);
+  f(0u);
+  for (auto& x : th) x.join();
+}
+
+// the whole fast path; returns 0 when the input needs the general path (out untouched except for scratch it frees)
+int pack_fast(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, int item_windows, unsigned nt,
+              const std::vector<int64_t>& cut, uint64_t total, pengk_packed* out) {
+  const uint64_t M = (uint64_t)item_windows;
+  if (PENGK_FRONT_PAD_BASES + total > ITEM_WS_MASK) return 0;  // the general path reports the range error
+  const uint64_t n_words = (PENGK_FRONT_PAD_BASES + total + 31) / 32 + 4;
+  uint64_t* words = (uint64_t*)calloc(n_words, sizeof(uint64_t));
+  if (!words) return 0;
+  std::vector<FastStat> st(nt);
+  run_ranges(nt, [&](unsigned t) {
+    fast_range(codes, offs, cut[t], cut[t + 1], W, M, PENGK_FRONT_PAD_BASES + (uint64_t)(offs[cut[t]] - offs[0]), words, st[t]);
+  });
+  uint64_t n_windows = 0, n_items = 0, bound = 0, max_len = 0;
+  std::vector<uint64_t> item0(nt);
+  uint64_t h3[64] = {0}, e1[16] = {0}, e0[4] = {0};
+  for (unsigned t = 0; t < nt; ++t) {
+    if (!st[t].ok) {
+      free(words);
+      return 0;
+    }
+    item0[t] = n_items;
+    n_windows += st[t].windows;
+    n_items += st[t].items;
+    bound += st[t].bound;
+    if (st[t].max_len > max_len) max_len = st[t].max_len;
+    for (int i = 0; i < 64; ++i) h3[i] += st[t].h3[i];
+    for (int i = 0; i < 16; ++i) e1[i] += st[t].e1[i];
+    for (int i = 0; i < 4; ++i) e0[i] += st[t].e0[i];
+  }
+  uint64_t* items = (uint64_t*)malloc((n_items ? n_items : 1) * sizeof(uint64_t));
+  if (!items) {
+    free(words);
+    return 0;
+  }
+  run_ranges(nt, [&](unsigned t) { fast_items(offs, cut[t], cut[t + 1], W, M, item0[t], items); });
+
+  // background counters (BaMM index: first base in the HIGH digit) from the 3-mer histogram and the head k-mers
+  int64_t* bg0 = out->bg_counts;
+  int64_t* bg1 = out->bg_counts + 4;
+  int64_t* bg2 = out->bg_counts + 20;
+  for (int x = 0; x < 64; ++x) {
+    const int a = x & 3, b = (x >> 2) & 3, c = x >> 4;  // a = first base
+    bg2[a * 16 + b * 4 + c] += (int64_t)h3[x];
+    bg1[b * 4 + c] += (int64_t)h3[x];
+  }
+  for (int y = 0; y < 16; ++y) bg1[y] += (int64_t)e1[y];
+  for (int y = 0; y < 16; ++y) bg0[y & 3] += bg1[y];
+  for (int b = 0; b < 4; ++b) bg0[b] += (int64_t)e0[b];
+
+  out->words = words;
+  out->items = items;
+  out->n_words = n_words;
+  out->n_items = n_items;
+  out->n_bases = total;
+  out->n_windows = n_windows;
+  out->max_bin_bound = bound;
+  out->n_sequences = (uint64_t)n_seq;
+  out->max_len = max_len;
+  out->W = W;
+  out->item_windows = item_windows;
+  out->all_whole = 1;
+  return 1;
+}
+
 }  // namespace
 
 extern "C" int pengk_pack(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, int item_windows,
@@ -153,6 +344,13 @@ extern "C" int pengk_pack(const uint8_t* codes, const int64_t* offs, int64_t n_s
       cut[t] = s;
     }
   }
+  try {
+    const char* g = getenv("PENGK_PACK_GENERAL");  // tests: compare the two paths
+    if (n_seq > 0 && !(g && atoi(g)) && pack_fast(codes, offs, n_seq, W, item_windows, nt, cut, total, out)) return PENGK_OK;
+  } catch (const std::exception&) {
+    return fail(PENGK_ERR_NOMEM, "pengk_pack: cannot start host threads");
+  }
+  memset(out, 0, sizeof *out);
   std::vector<RangeStat> st(nt);
   try {
     std::vector<std::thread> th;

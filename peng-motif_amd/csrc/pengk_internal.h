@@ -36,6 +36,7 @@ struct pengk_ctx {
   size_t count_aux_bytes = 0;
   uint64_t n_windows_hint = 0;  // total windows of the attached items (0 = unknown: n_items * item_windows)
   uint64_t key_cap_override = 0; // test hook: entries per bucket region (0 = sized from the window count)
+  uint64_t iupac_group_bytes = 0; // test hook: scratch budget of one group of large K4 patterns (0 = 1 GiB)
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms
 };
 

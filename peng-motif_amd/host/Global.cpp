@@ -1,5 +1,7 @@
 #include "Global.h"
 
+#include "device.h"
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +43,7 @@ int Global::maximum_optimized_patterns = 50;
 void Global::init(int nargs, char* args[]) {
   readArguments(nargs, args);
   Alphabet::init(alphabetType);
+  pengk_host::start_context();  // the device runtime starts while the FASTA files are read
   // both strands are handled inside the count; sequences are always read single stranded
   inputSequenceSet = new SequenceSet(inputSequenceFilename, true);
   backgroundSequenceSet =

@@ -8,6 +8,7 @@
 #include <iomanip>
 #include <iostream>
 
+#include "ranked_prefix.h"
 #include "utils.h"
 
 using pengk_host::check;
@@ -28,8 +29,10 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
   const size_t NP = number_patterns;
 
   // ---- sequences -> 2-bit stream + scan items (host packer resolves the N / skip scan rule) ----------
+  pengk_host::Lap lap("    ");
   pengk_packed pk;
   check(pengk_pack(sequence_set->codes(), sequence_set->offsets(), (int64_t)sequence_set->getN(), W, 0, &pk), "pengk_pack");
+  lap("pack");
   pengk_host::DeviceBuffer<uint64_t> d_words(pk.n_words), d_items(pk.n_items + 1), d_ltot(1);
   d_words.upload(pk.words, pk.n_words);
   if (pk.n_items) d_items.upload(pk.items, pk.n_items);
@@ -38,6 +41,7 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
         "pengk_set_sequences");
   check(pengk_set_option(context(), "n_windows_hint", (int64_t)pk.n_windows), "pengk_set_option");
   pengk_packed_free(&pk);
+  lap("upload");
 
   // ---- K1 count (+ twin copy), K2+K3 sweep ---------------------------------------------------------------
   d_counts.resize(NP);
@@ -56,36 +60,37 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
                             d_expected.get(), d_logp.get(), d_z.get()),
         "pengk_pattern_stats");
 
+  if (lap.on) check(pengk_synchronize(context()), "pengk_synchronize");
+  lap("count + sweep");
   // ---- host mirrors behind the raw-pointer getters ---------------------------------------------------------
-  pattern_counter = new size_t[NP];
-  {
-    std::vector<uint32_t> c32(NP);
-    d_counts.download(c32.data(), NP);
-    for (size_t i = 0; i < NP; ++i) pattern_counter[i] = c32[i];
-  }
-  uint64_t lt = 0;
-  d_ltot.download(&lt, 1);
-  ltot = lt;
+  // one page-locked slab: size_t counts | float bgprob[max_k+1] | expected | log-p | z | uint32 staging for the counts
+  const size_t n_float = (size_t)(this->max_k + 1) * NP + 3 * NP;
+  void* slab = nullptr;
+  check(pengk_host_alloc(context(), NP * sizeof(size_t) + n_float * sizeof(float) + NP * sizeof(uint32_t), &slab), "pengk_host_alloc");
+  host_tables = slab;
+  pattern_counter = (size_t*)slab;
+  float* f = (float*)(pattern_counter + NP);
   pattern_bg_probabilities = new float*[this->max_k + 1];
-  for (int o = 0; o <= this->max_k; ++o) {
-    pattern_bg_probabilities[o] = new float[NP];
-    d_bgprob.download(pattern_bg_probabilities[o], NP, (size_t)o * NP);
-  }
-  expected_counts = new float[NP];
-  pattern_logp = new float[NP];
-  pattern_zscore = new float[NP];
+  for (int o = 0; o <= this->max_k; ++o) pattern_bg_probabilities[o] = f + (size_t)o * NP;
+  expected_counts = f + (size_t)(this->max_k + 1) * NP;
+  pattern_logp = expected_counts + NP;
+  pattern_zscore = pattern_logp + NP;
+  uint32_t* c32 = (uint32_t*)(pattern_zscore + NP);
+  d_counts.download(c32, NP);
+  d_bgprob.download(f, (size_t)(this->max_k + 1) * NP);
   d_expected.download(expected_counts, NP);
   d_logp.download(pattern_logp, NP);
   d_z.download(pattern_zscore, NP);
+  for (size_t i = 0; i < NP; ++i) pattern_counter[i] = c32[i];
+  uint64_t lt = 0;
+  d_ltot.download(&lt, 1);
+  ltot = lt;
+  lap("tables to host");
 }
 
 BasePattern::~BasePattern() {
-  delete[] pattern_counter;
-  for (int o = 0; o <= max_k; ++o) delete[] pattern_bg_probabilities[o];
+  check(pengk_host_free(context(), host_tables), "pengk_host_free");
   delete[] pattern_bg_probabilities;
-  delete[] pattern_logp;
-  delete[] pattern_zscore;
-  delete[] expected_counts;
   delete[] factor;
 }
 
@@ -145,11 +150,11 @@ std::vector<size_t> BasePattern::select_base_patterns(const float zscore_thresho
                                                       bool single_stranded, bool filter_neighbors) {
   std::vector<size_t> selected;
   std::vector<char> seen(number_patterns, 0);
-  size_t* order = new size_t[number_patterns];
-  for (size_t i = 0; i < number_patterns; ++i) order[i] = i;
-  std::sort(order, order + number_patterns, sort_indices(pattern_zscore));
-  for (size_t r = 0; r < number_patterns; ++r) {
-    const size_t x = order[r];
+  // the ranking std::sort(order, sort_indices(pattern_zscore)) would leave (:458), down to the threshold only
+  std::vector<ranked_prefix::Entry> order;
+  const size_t n_ranked = ranked_prefix::rank(pattern_zscore, number_patterns, zscore_threshold, order);
+  for (size_t r = 0; r < n_ranked; ++r) {
+    const size_t x = order[r].id;
     if (pattern_zscore[x] < zscore_threshold) break;
     if (pattern_counter[x] < count_threshold) continue;
     if (seen[x] || (!single_stranded && seen[getFastRevCompId(x)])) continue;
@@ -161,7 +166,6 @@ std::vector<size_t> BasePattern::select_base_patterns(const float zscore_thresho
         for (size_t c = 0; c < 4; ++c) seen[masked | (c << (2 * p))] = 1;
       }
   }
-  delete[] order;
   return selected;
 }
 

@@ -76,6 +76,7 @@ class BasePattern {
 
   size_t* factor;
   size_t pattern_length;
+  void* host_tables = nullptr;  // page-locked slab behind the five table pointers below
   size_t* pattern_counter;
   float** pattern_bg_probabilities;
   float* pattern_logp;

@@ -2,6 +2,8 @@
 
 #include <cstdlib>
 #include <iostream>
+#include <string>
+#include <thread>
 
 #include "Global.h"
 
@@ -15,7 +17,32 @@ void check(int rc, const char* what) {
   exit(1);
 }
 
+// Context creation (HIP runtime start-up + code object load, ~0.2 s) can run beside the FASTA reader.
+static std::thread g_starter;
+static int g_starter_rc = PENGK_OK;
+static std::string g_starter_error;
+
+static void join_starter() {
+  if (g_starter.joinable()) g_starter.join();
+}
+
+void start_context() {
+  if (g_ctx || g_starter.joinable()) return;
+  g_starter = std::thread([] {
+    g_starter_rc = pengk_create(Global::device, &g_ctx);
+    if (g_starter_rc != PENGK_OK) g_starter_error = pengk_last_error();  // the message is thread local
+  });
+  atexit(join_starter);  // an exit() on a FASTA error must not tear the process down under a starting runtime
+}
+
 pengk_ctx* context() {
+  if (g_starter.joinable()) {
+    g_starter.join();
+    if (g_starter_rc != PENGK_OK) {
+      std::cerr << "Error: pengk_create failed: " << pengk_error_name(g_starter_rc) << ": " << g_starter_error << std::endl;
+      exit(1);
+    }
+  }
   if (!g_ctx) check(pengk_create(Global::device, &g_ctx), "pengk_create");
   return g_ctx;
 }

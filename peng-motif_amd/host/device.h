@@ -4,16 +4,35 @@
 #ifndef PENGK_HOST_DEVICE_H_
 #define PENGK_HOST_DEVICE_H_
 
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <iostream>
 
 #include "pengk.h"
 
 namespace pengk_host {
 
 pengk_ctx* context();           // created on first use on Global::device
+void start_context();           // optional: begin creating it on a helper thread; context() waits for it
 void shutdown();
 void check(int rc, const char* what);
+
+// PENGK_TIMING=1: wall-clock report of sub-phases on stderr (stdout stays the reference's trace)
+struct Lap {
+  using clk = std::chrono::steady_clock;
+  const char* indent;
+  bool on = std::getenv("PENGK_TIMING") != nullptr;
+  clk::time_point last = clk::now();
+  explicit Lap(const char* ind = "  ") : indent(ind) {}
+  void operator()(const char* what) {
+    if (!on) return;
+    const auto now = clk::now();
+    std::cerr << "[timing] " << indent << what << ": " << std::chrono::duration<double>(now - last).count() << " s" << std::endl;
+    last = now;
+  }
+};
 
 template <class T>
 class DeviceBuffer {

@@ -9,6 +9,7 @@
 #include <iomanip>
 #include <iostream>
 #include <limits>
+#include <map>
 
 #include "base_pattern.h"
 #include "device.h"
@@ -107,8 +108,20 @@ void Peng::filter_redundancy(const float merge_bit_factor_threshold, std::vector
 }
 
 // ---- greedy pairwise merging (src/peng.cpp:237-313) ----------------------------------------------------------
+// The reference recomputes the similarity of EVERY pair after each merge (O(merges * n^2 * W * shifts)); a pair's
+// score depends on the two motifs only, so scores are kept per pair of motif serial numbers and only the pairs of the
+// newly merged motif are evaluated in later rounds.  Scan order and the strict `>` tie-break are the reference's.
 void Peng::merge_iupac_patterns(const size_t pattern_length, const float threshold_factor, BackgroundModel*,
                                 std::vector<IUPACPattern*>& pats, size_t max_merged_length) {
+  struct Similarity {
+    float score;
+    int shift;
+    bool comp;
+  };
+  std::map<std::pair<size_t, size_t>, Similarity> known;  // (serial of pats[i], serial of pats[j]), i < j
+  std::vector<size_t> serial(pats.size());
+  size_t next_serial = 0;
+  for (size_t& x : serial) x = next_serial++;
   for (;;) {
     float best_score = -std::numeric_limits<float>::infinity();
     size_t bi = 0, bj = 0;
@@ -118,13 +131,18 @@ void Peng::merge_iupac_patterns(const size_t pattern_length, const float thresho
       if (pats[i]->getLogPval() > -5) continue;
       for (size_t j = i + 1; j < pats.size(); ++j) {
         if (pats[j]->getLogPval() > -5) continue;
-        auto res = IUPACPattern::calculate_S(pats[i], pats[j], strand, bg_model->getV()[0]);
-        if (std::get<0>(res) > best_score) {
-          best_score = std::get<0>(res);
+        const auto key = std::make_pair(serial[i], serial[j]);
+        auto it = known.find(key);
+        if (it == known.end()) {
+          auto res = IUPACPattern::calculate_S(pats[i], pats[j], strand, bg_model->getV()[0]);
+          it = known.emplace(key, Similarity{std::get<0>(res), std::get<1>(res), std::get<2>(res)}).first;
+        }
+        if (it->second.score > best_score) {
+          best_score = it->second.score;
           bi = i;
           bj = j;
-          best_shift = std::get<1>(res);
-          best_comp = std::get<2>(res);
+          best_shift = it->second.shift;
+          best_comp = it->second.comp;
         }
       }
     }
@@ -149,6 +167,9 @@ void Peng::merge_iupac_patterns(const size_t pattern_length, const float thresho
     pats.erase(pats.begin() + bj);
     pats.erase(pats.begin() + bi);
     pats.push_back(merged);
+    serial.erase(serial.begin() + bj);
+    serial.erase(serial.begin() + bi);
+    serial.push_back(next_serial++);
   }
 }
 
@@ -165,12 +186,15 @@ void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupa
   print_status("Processing kmers of length " + std::to_string(W), false);
   print_status("Finding overrepresented kmers (base patterns)", false);
   const int cur_k = std::min((int)W - 1, k), cur_max_k = std::min((int)W - 1, max_k);
+  pengk_host::Lap lap;
   BasePattern* base = new BasePattern(W, strand, cur_k, cur_max_k, sequence_set, bg_model);
   size_t* counter = base->getPatternCounter();
+  lap("base patterns (pack, upload, count, sweep, tables to host)");
 
   auto seeds = base->select_base_patterns(params.zscore_threshold, params.count_threshold, strand == Strand::PLUS_STRAND,
                                           params.filter_neighbors);
   if (seeds.empty()) std::cout << "No overrepresented seed patterns found. Stopping." << std::endl;
+  lap("seed selection");
   base->print_patterns(seeds);
 
   print_status("Optimizing base patterns");
@@ -179,6 +203,7 @@ void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupa
   std::vector<IUPACPattern*> unoptimized;
   optimize_iupac_patterns(params.opt_score_type, base, seeds, unoptimized, params.enrich_pseudocount_factor);
   std::cout << std::endl;
+  lap("hill-climb");
 
   print_status("Filtering degenerated IUPAC patterns");
   filter_iupac_patterns(W, params.minimum_processed_motifs, unoptimized);
@@ -198,6 +223,7 @@ void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupa
               << "   [ avg. info: " << std::setprecision(2) << avg_info << " ]" << std::endl;
   }
 
+  lap("filter + PWMs");
   print_status("Optimizing expectation-maximization / merging patterns");
   {
     const int background = max_k > (int)W - 1 ? (int)W - 1 : max_k;
@@ -210,6 +236,7 @@ void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupa
       optimized = std::move(unoptimized);
       unoptimized.clear();
     }
+    lap("EM");
     if (params.use_merging) {
       if (W >= (size_t)MIN_MERGE_OVERLAP) {
         merge_iupac_patterns(W, params.bit_factor_merge_threshold, bg_model, optimized, params.max_merged_length);
@@ -217,6 +244,7 @@ void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupa
         std::cerr << "Warning: Specified pattern length (" << W << ") is too low for merging!" << std::endl;
       }
     }
+    lap("merging");
     for (IUPACPattern* p : optimized) {
       p->set_optimization_bg_model_order(max_k);
       best_iupac_patterns.push_back(p);
@@ -227,9 +255,13 @@ void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupa
 }
 
 // ---- hill-climb in IUPAC space (src/peng.cpp:437-541) -----------------------------------------------------------
-// Per round all single-letter mutants of the current mother are scored in ONE device launch; the
-// accept/reject decisions then replay in the reference's order (position-major, neighbourhood order)
-// on the same float scores, so the walk is identical.
+// The reference climbs seed after seed; a climb scores all single-letter mutants of its current mother per round
+// and ends when no mutant is better -- or when its best pattern was already met by an EARLIER seed's climb (:504-514).
+// Only that second test couples the seeds, and it can only end a climb sooner.  So all climbs advance in lockstep here,
+// ignoring it: every round scores the mutants of every still-improving seed in ONE device launch (K4), on the same
+// float scores and in the reference's order (position-major, neighbourhood order) within a seed.  Afterwards the
+// recorded rounds are replayed seed by seed with the `seen` bookkeeping, cutting each climb where the reference would
+// have stopped it; output and result are those of the sequential walk.
 void Peng::optimize_iupac_patterns(OPTIMIZATION_SCORE score_type, BasePattern* base_patterns,
                                    std::vector<size_t>& selected_base_patterns, std::vector<IUPACPattern*>& best_iupac_patterns,
                                    float enrich_pseudocount_factor) {
@@ -237,41 +269,87 @@ void Peng::optimize_iupac_patterns(OPTIMIZATION_SCORE score_type, BasePattern* b
   const size_t W = base_patterns->getPatternLength();
   const size_t pseudo_expected = (size_t)(sequence_set->getN() * enrich_pseudocount_factor);
 
-  for (size_t seed : selected_base_patterns) {
-    IUPACPattern* best_mutant = new IUPACPattern(base_patterns->baseId2IUPACId(seed), W);
-    best_mutant->aggregate_attributes_from_basepatterns(base_patterns);
-    float best_score = base_patterns->getOptimizationScore(score_type, seed, pseudo_expected);
-    print_row(best_mutant, W, best_score, true);
-
-    bool found_better = true;
-    while (found_better) {
-      found_better = false;
-      const size_t mother = best_mutant->get_pattern();
-      std::vector<IUPACPattern*> mutants;
+  struct Round {
+    std::vector<std::pair<IUPACPattern*, float>> accepted;  // every improvement of the round, in the order it was found
+    std::set<size_t> mutants;                              // all patterns scored in the round
+  };
+  struct Climb {
+    IUPACPattern* start = nullptr;
+    float start_score = 0;
+    IUPACPattern* mother = nullptr;  // best pattern so far (not owned twice: it is `start` or an accepted mutant)
+    float score = 0;
+    bool improving = true;
+    std::vector<Round> rounds;
+  };
+  std::vector<Climb> climbs(selected_base_patterns.size());
+  {
+    std::vector<IUPACPattern*> starts;
+    for (size_t s = 0; s < climbs.size(); ++s) {
+      climbs[s].start = climbs[s].mother = new IUPACPattern(base_patterns->baseId2IUPACId(selected_base_patterns[s]), W);
+      starts.push_back(climbs[s].start);
+    }
+    IUPACPattern::aggregate_batch(base_patterns, starts);
+    for (size_t s = 0; s < climbs.size(); ++s)
+      climbs[s].start_score = climbs[s].score = base_patterns->getOptimizationScore(score_type, selected_base_patterns[s], pseudo_expected);
+  }
+  for (;;) {
+    std::vector<IUPACPattern*> mutants;
+    std::vector<size_t> first_of(climbs.size() + 1, 0);
+    for (size_t s = 0; s < climbs.size(); ++s) {
+      first_of[s] = mutants.size();
+      if (!climbs[s].improving) continue;
+      const size_t mother = climbs[s].mother->get_pattern();
       for (size_t p = 0; p < W; ++p) {
         const int c = IUPACPattern::getNucleotideAtPos(mother, p);
         const size_t masked = mother - c * IUPACPattern::iupac_factor[p];
         for (int r : IUPACAlphabet::similar(c)) mutants.push_back(new IUPACPattern(masked + r * IUPACPattern::iupac_factor[p], W));
       }
-      IUPACPattern::aggregate_batch(base_patterns, mutants);
-      std::set<size_t> current_seen;
-      for (IUPACPattern* m : mutants) {
-        current_seen.insert(m->get_pattern());
+    }
+    first_of[climbs.size()] = mutants.size();
+    if (mutants.empty()) break;
+    IUPACPattern::aggregate_batch(base_patterns, mutants);
+    for (size_t s = 0; s < climbs.size(); ++s) {
+      Climb& c = climbs[s];
+      if (!c.improving) continue;
+      Round round;
+      for (size_t i = first_of[s]; i < first_of[s + 1]; ++i) {
+        IUPACPattern* m = mutants[i];
+        round.mutants.insert(m->get_pattern());
         const float score = m->getOptimizationScore(score_type, pseudo_expected, (unsigned)n_sequences);
-        if (score < best_score) {
-          delete best_mutant;
-          best_mutant = m;
-          best_score = score;
-          found_better = true;
-          print_row(best_mutant, W, best_score, true);
+        if (score < c.score) {
+          round.accepted.emplace_back(m, score);
+          c.mother = m;
+          c.score = score;
         } else {
           delete m;
         }
       }
-      if (seen.count(best_mutant->get_pattern()) == 1) found_better = false;
-      current_seen.erase(best_mutant->get_pattern());
-      seen.insert(current_seen.begin(), current_seen.end());
+      c.improving = !round.accepted.empty();
+      c.rounds.push_back(std::move(round));
     }
+  }
+
+  for (size_t s = 0; s < climbs.size(); ++s) {
+    Climb& c = climbs[s];
+    const size_t seed = selected_base_patterns[s];
+    IUPACPattern* best_mutant = c.start;
+    print_row(best_mutant, W, c.start_score, true);
+    size_t used = 0;
+    for (Round& round : c.rounds) {
+      ++used;
+      for (auto& a : round.accepted) {
+        delete best_mutant;
+        best_mutant = a.first;
+        print_row(best_mutant, W, a.second, true);
+      }
+      bool found_better = !round.accepted.empty();
+      if (seen.count(best_mutant->get_pattern()) == 1) found_better = false;
+      round.mutants.erase(best_mutant->get_pattern());
+      seen.insert(round.mutants.begin(), round.mutants.end());
+      if (!found_better) break;
+    }
+    for (size_t r = used; r < c.rounds.size(); ++r)  // rounds the reference would not have run
+      for (auto& a : c.rounds[r].accepted) delete a.first;
 
     if (best.count(best_mutant->get_pattern()) == 0 && seen.count(best_mutant->get_pattern()) == 0) {
       best_iupac_patterns.push_back(best_mutant);

@@ -153,3 +153,61 @@ def test_packer_is_thread_count_invariant(monkeypatch):
             assert np.array_equal(p.bg_counts, po.bg_counts(codes, offs, 2))
         else:
             assert cur == ref, nt
+
+
+@pytest.mark.parametrize("W,M", [(4, 64), (8, 64), (10, 256), (14, 100)])
+def test_packer_one_pass_path_equals_the_general_path(monkeypatch, W, M):
+    """inputs made of whole runs only (no invalid base, every L >= W) take the one-pass packer: its stream, items
+    and counters must be those of the general two-pass packer, for any thread count and ragged lengths"""
+    rng = np.random.default_rng(100 + W)
+    lens = rng.integers(W, 700, size=4000)
+    lens[:50] = W  # exactly one window
+    lens[50:60] = rng.integers(2000, 5000, size=10)  # several items per sequence
+    codes = rng.integers(1, 5, size=int(lens.sum())).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+    def snapshot():
+        p = pk.Packed(codes, offs, W, M)
+        return (p.words.tobytes(), p.items.tobytes(), p.bg_counts.tobytes(), p.n_windows, p.n_bases, p.max_bin_bound, p.all_whole,
+                p.max_len, p.n_sequences)
+
+    monkeypatch.setenv("PENGK_PACK_GENERAL", "1")
+    monkeypatch.setenv("PENGK_PACK_THREADS", "3")
+    want = snapshot()
+    assert want[6] == 1
+    monkeypatch.setenv("PENGK_PACK_GENERAL", "0")
+    for nt in (1, 2, 5, 16):
+        monkeypatch.setenv("PENGK_PACK_THREADS", str(nt))
+        assert snapshot() == want, nt
+    assert np.array_equal(pk.Packed(codes, offs, W, M).bg_counts, po.bg_counts(codes, offs, 2))
+
+
+def test_packer_one_pass_path_gives_way_on_any_irregular_sequence(monkeypatch):
+    """one invalid base (anywhere, incl. the last byte) or one sequence shorter than W sends the whole input down the
+    general path; the result must not depend on which path was tried first"""
+    rng = np.random.default_rng(77)
+    W = 8
+    lens = rng.integers(W, 300, size=500)
+    base = rng.integers(1, 5, size=int(lens.sum())).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for where, val in ((0, 0), (len(base) - 1, 0), (len(base) // 2, 7), (int(offs[250]) + 3, 200), (int(offs[100 + 1]) - 1, 0)):
+        codes = base.copy()
+        codes[where] = val
+        monkeypatch.setenv("PENGK_PACK_GENERAL", "1")
+        a = pk.Packed(codes, offs, W, 64)
+        monkeypatch.setenv("PENGK_PACK_GENERAL", "0")
+        b = pk.Packed(codes, offs, W, 64)
+        assert a.all_whole == 0 and b.all_whole == 0
+        assert a.words.tobytes() == b.words.tobytes() and a.items.tobytes() == b.items.tobytes()
+        assert np.array_equal(a.bg_counts, b.bg_counts) and a.n_windows == b.n_windows
+        if val == 0:  # the reader only produces codes 0..4; larger bytes are merely 'invalid' to the packer
+            assert np.array_equal(b.bg_counts, po.bg_counts(codes, offs, 2))
+    lens2 = lens.copy()
+    lens2[123] = W - 1
+    offs2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int64)
+    codes2 = base[:int(lens2.sum())]
+    monkeypatch.setenv("PENGK_PACK_GENERAL", "1")
+    a = pk.Packed(codes2, offs2, W, 64)
+    monkeypatch.setenv("PENGK_PACK_GENERAL", "0")
+    b = pk.Packed(codes2, offs2, W, 64)
+    assert a.all_whole == 0 and b.all_whole == 0 and a.words.tobytes() == b.words.tobytes() and a.items.tobytes() == b.items.tobytes()

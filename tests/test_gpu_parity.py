@@ -439,3 +439,42 @@ def test_em_many_pwms_batch(ctx, golden_dir):
     for i in range(0, len(order), 7):
         p1, it1, _ = po.em(W, r["counts"], r["bgp"][K], pwms[i], 1e4, 0.0, 3, mode=1, final_norm=False)
         assert np.abs(pw[i].astype(np.float64) - p1).max() <= 1e-6
+
+
+@pytest.mark.parametrize("both", [True, False])
+def test_iupac_many_large_patterns_in_one_call(ctx, both):
+    """N-rich patterns (more members than one workgroup sorts in LDS) take the grouped bitmap / compact / gather / fold
+    pipeline, many patterns per round of launches; mixed with small ones, in any order, over several groups (the scratch
+    budget is squeezed so that the call needs more than one), every row must equal the oracle's serial sums bit for bit."""
+    W = 8
+    rng = np.random.default_rng(31 + both)
+    codes, offs = po.synth(1, 0, 20000, 120)
+    counts, ltot = po.count(codes, offs, W, both)
+    V = po.bg_V(po.bg_counts(codes, offs, 2), 2)
+    bgp = po.bgprob(W, 2, V, both)
+    stats = po.stats(W, counts, bgp, ltot)
+    expected = stats[0] if isinstance(stats, tuple) else stats["expected"]
+    letters = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+    ids = []
+    for _ in range(60):
+        n_N = rng.integers(3, 9)  # 3..8 positions are N: 2^6 .. 4^8 members
+        pos_N = rng.choice(W, size=n_N, replace=False)
+        ls = rng.choice(letters, size=W)
+        ls[pos_N] = 10
+        ids.append(sum(int(l) * 11 ** i for i, l in enumerate(ls)))
+    ids.append(sum(10 * 11 ** i for i in range(W)))  # all N
+    ids = np.array(ids, dtype=np.uint64)
+    d_counts = pk.DeviceArray.from_host(ctx, counts.astype(np.uint32))
+    d_bgp = pk.DeviceArray.from_host(ctx, bgp.astype(np.float32))
+    d_exp = pk.DeviceArray.from_host(ctx, np.asarray(expected, np.float32))
+    want = [po.iupac_aggregate(int(i), W, both, counts, bgp, expected) for i in ids]
+    for budget in (0, 3 << 20):
+        ctx.set_option("iupac_group_bytes", budget)
+        out = ctx.iupac_aggregate(W, both, ids, d_counts, d_bgp, d_exp)
+        for j, w in enumerate(want):
+            assert int(out["sites"][j]) == w.sites, (budget, j)
+            for f in ("bg_p", "expected", "zscore", "log_pvalue"):
+                a = np.float32(out[f][j]).view(np.uint32)
+                b = np.float32(getattr(w, f)).view(np.uint32)
+                assert a == b, (budget, j, f, po.iupac_str(int(ids[j]), W))
+    ctx.set_option("iupac_group_bytes", 0)

@@ -83,3 +83,14 @@ def test_reader_error_exits(tmp_path):
         subprocess.run(["make", "-s", "-C", os.path.dirname(DUMP), "host_ingest_dump"], check=True)
         r = subprocess.run([DUMP, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 1
+
+
+def test_seed_ranking_replays_std_sort():
+    """select_base_patterns ranks with ranked_prefix.h (a replay of libstdc++'s introsort that stops below the z
+    threshold); the reference ranks with std::sort (src/base_pattern.cpp:458).  The CPU-only harness compares the two on
+    this machine's libstdc++ for tables full of exact ties (reverse-complement pairs), +inf and NaN scores."""
+    host = os.path.dirname(DUMP)
+    subprocess.run(["make", "-s", "-C", host, "ranked_prefix_test"], check=True)
+    r = subprocess.run([os.path.join(host, "ranked_prefix_test")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()
+    assert r.stdout.decode().startswith("ok ")
