@@ -52,7 +52,9 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
   for (int o = 0, at = 0; o <= 2; at += 1 << (2 * (o + 1)), ++o)
     if (o <= bg->getOrder())
       for (int y = 0; y < (1 << (2 * (o + 1))); ++y) hV[at + y] = bg->getV()[o][y];
-  pengk_host::DeviceBuffer<float> d_V(84), d_logp(NP), d_z(NP);
+  pengk_host::DeviceBuffer<float> d_V(84);
+  d_logp.resize(NP);
+  d_z.resize(NP);
   d_V.upload(hV, 84);
   d_bgprob.resize((size_t)(this->max_k + 1) * NP);
   d_expected.resize(NP);
@@ -62,36 +64,68 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
 
   if (lap.on) check(pengk_synchronize(context()), "pengk_synchronize");
   lap("count + sweep");
-  // ---- host mirrors behind the raw-pointer getters ---------------------------------------------------------
-  // one page-locked slab: size_t counts | float bgprob[max_k+1] | expected | log-p | z | uint32 staging for the counts
-  const size_t n_float = (size_t)(this->max_k + 1) * NP + 3 * NP;
-  void* slab = nullptr;
-  check(pengk_host_alloc(context(), NP * sizeof(size_t) + n_float * sizeof(float) + NP * sizeof(uint32_t), &slab), "pengk_host_alloc");
-  host_tables = slab;
-  pattern_counter = (size_t*)slab;
-  float* f = (float*)(pattern_counter + NP);
-  pattern_bg_probabilities = new float*[this->max_k + 1];
-  for (int o = 0; o <= this->max_k; ++o) pattern_bg_probabilities[o] = f + (size_t)o * NP;
-  expected_counts = f + (size_t)(this->max_k + 1) * NP;
-  pattern_logp = expected_counts + NP;
-  pattern_zscore = pattern_logp + NP;
-  uint32_t* c32 = (uint32_t*)(pattern_zscore + NP);
-  d_counts.download(c32, NP);
-  d_bgprob.download(f, (size_t)(this->max_k + 1) * NP);
-  d_expected.download(expected_counts, NP);
-  d_logp.download(pattern_logp, NP);
-  d_z.download(pattern_zscore, NP);
-  for (size_t i = 0; i < NP; ++i) pattern_counter[i] = c32[i];
   uint64_t lt = 0;
   d_ltot.download(&lt, 1);
   ltot = lt;
-  lap("tables to host");
 }
 
 BasePattern::~BasePattern() {
-  check(pengk_host_free(context(), host_tables), "pengk_host_free");
+  void* tables[] = {pattern_counter, pattern_bg_probabilities ? pattern_bg_probabilities[0] : nullptr, pattern_logp, pattern_zscore,
+                    expected_counts};
+  for (void* t : tables)
+    if (t) check(pengk_host_free(context(), t), "pengk_host_free");
   delete[] pattern_bg_probabilities;
   delete[] factor;
+}
+
+// ---- host mirrors behind the raw-pointer getters (page-locked: the copy runs at link speed) -----------------
+float* BasePattern::fetch(const float* d_src, size_t n) {
+  void* h = nullptr;
+  check(pengk_host_alloc(context(), n * sizeof(float), &h), "pengk_host_alloc");
+  check(pengk_memcpy_d2h(context(), h, d_src, n * sizeof(float)), "pengk_memcpy_d2h");
+  return (float*)h;
+}
+
+size_t* BasePattern::host_counts() {
+  if (!pattern_counter) {
+    const size_t NP = number_patterns;
+    void* h = nullptr;
+    check(pengk_host_alloc(context(), NP * sizeof(size_t), &h), "pengk_host_alloc");
+    // the 32-bit device counts land in the upper half and are widened in place, front to back
+    const uint32_t* c32 = (const uint32_t*)h + NP;
+    check(pengk_memcpy_d2h(context(), (void*)c32, d_counts.get(), NP * sizeof(uint32_t)), "pengk_memcpy_d2h");
+    size_t* out = (size_t*)h;
+    for (size_t i = 0; i < NP; ++i) {
+      const uint32_t c = c32[i];
+      out[i] = c;
+    }
+    pattern_counter = out;
+  }
+  return pattern_counter;
+}
+
+float** BasePattern::host_bgprob() {
+  if (!pattern_bg_probabilities) {
+    float* all = fetch(d_bgprob.get(), (size_t)(max_k + 1) * number_patterns);
+    pattern_bg_probabilities = new float*[max_k + 1];
+    for (int o = 0; o <= max_k; ++o) pattern_bg_probabilities[o] = all + (size_t)o * number_patterns;
+  }
+  return pattern_bg_probabilities;
+}
+
+float* BasePattern::host_logp() {
+  if (!pattern_logp) pattern_logp = fetch(d_logp.get(), number_patterns);
+  return pattern_logp;
+}
+
+float* BasePattern::host_zscore() {
+  if (!pattern_zscore) pattern_zscore = fetch(d_z.get(), number_patterns);
+  return pattern_zscore;
+}
+
+float* BasePattern::host_expected() {
+  if (!expected_counts) expected_counts = fetch(d_expected.get(), number_patterns);
+  return expected_counts;
 }
 
 void BasePattern::init(size_t pattern_length) {
@@ -125,12 +159,12 @@ size_t BasePattern::baseId2IUPACId(const size_t base_pattern) {
 }
 
 float BasePattern::getExpCountFraction(const size_t pattern, const size_t pseudo_expected_pattern_counts) {
-  return (expected_counts[pattern] + (float)pseudo_expected_pattern_counts) / (float)pattern_counter[pattern];
+  return (host_expected()[pattern] + (float)pseudo_expected_pattern_counts) / (float)host_counts()[pattern];
 }
 
 float BasePattern::getMutualInformationScore(const size_t pattern) {
-  const unsigned int observed = (unsigned int)pattern_counter[pattern];
-  return mutual_information_score((float)observed, expected_counts[pattern], (unsigned int)n_sequences);
+  const unsigned int observed = (unsigned int)host_counts()[pattern];
+  return mutual_information_score((float)observed, host_expected()[pattern], (unsigned int)n_sequences);
 }
 
 float BasePattern::getOptimizationScore(const OPTIMIZATION_SCORE score_type, const size_t pattern,
@@ -152,6 +186,8 @@ std::vector<size_t> BasePattern::select_base_patterns(const float zscore_thresho
   std::vector<char> seen(number_patterns, 0);
   // the ranking std::sort(order, sort_indices(pattern_zscore)) would leave (:458), down to the threshold only
   std::vector<ranked_prefix::Entry> order;
+  const float* pattern_zscore = host_zscore();
+  const size_t* pattern_counter = host_counts();
   const size_t n_ranked = ranked_prefix::rank(pattern_zscore, number_patterns, zscore_threshold, order);
   for (size_t r = 0; r < n_ranked; ++r) {
     const size_t x = order[r].id;
@@ -181,6 +217,9 @@ void BasePattern::print_patterns(std::vector<size_t> patterns) {
             << "\t" << std::setw(15) << "zscore" << std::endl
             << std::endl;
   std::cout << std::fixed << std::setprecision(2);
+  const size_t* pattern_counter = host_counts();
+  const float* expected_counts = host_expected();
+  const float* pattern_zscore = host_zscore();
   for (size_t x : patterns)
     std::cout << std::setw(15) << toString(x) << "\t" << std::setw(15) << pattern_counter[x] << "\t" << std::setw(15)
               << (pattern_counter[x] / expected_counts[x]) << "\t" << std::setw(15) << pattern_zscore[x] << std::endl;

@@ -1,7 +1,8 @@
 // BasePattern -- all 4^W base patterns of one length: counts, background probabilities, expected
 // counts, log-p and z-scores.  Public surface of the reference's src/base_pattern.h (borrowed raw host
 // pointers with the same element types); the tables are produced by the HIP kernels behind
-// include/pengk.h and mirrored into host arrays once.
+// include/pengk.h; a table is mirrored into a (page-locked) host array the first time it is asked for, so a
+// run pays the device-to-host copy only for the tables it reads (the pipeline: counts, expected, z).
 //
 // ids: little-endian base 4, A C G T = 0..3 ("ATGC" = 0 + 3*4 + 2*16 + 1*64).
 #ifndef PENGK_HOST_BASE_PATTERN_H_
@@ -35,13 +36,13 @@ class BasePattern {
   size_t getFastRevCompId(const size_t pattern_id);
   size_t getNumberPatterns() { return number_patterns; }
   int getBackgroundOrder() const { return k; }
-  float* getExpectedCounts() const { return expected_counts; }
-  size_t* getPatternCounter() { return pattern_counter; }
-  float* getBackgroundProb(const int order) { return pattern_bg_probabilities[order]; }
-  float* getBackgroundProb() { return pattern_bg_probabilities[k]; }
+  float* getExpectedCounts() { return host_expected(); }
+  size_t* getPatternCounter() { return host_counts(); }
+  float* getBackgroundProb(const int order) { return host_bgprob()[order]; }
+  float* getBackgroundProb() { return host_bgprob()[k]; }
   size_t baseId2IUPACId(const size_t base_pattern);
   float getExpCountFraction(const size_t pattern, const size_t pseudo_expected_pattern_counts);
-  float getLogPval(size_t pattern) { return pattern_logp[pattern]; }
+  float getLogPval(size_t pattern) { return host_logp()[pattern]; }
   float getOptimizationScore(const OPTIMIZATION_SCORE score_type, const size_t pattern,
                              const size_t pseudo_expected_pattern_counts);
   size_t getLtot() { return ltot; }
@@ -74,14 +75,21 @@ class BasePattern {
  private:
   float getMutualInformationScore(size_t pattern);
 
+  // host mirrors (borrowed by the getters above, valid for the object's life), fetched on first use
+  size_t* host_counts();
+  float** host_bgprob();
+  float* host_logp();
+  float* host_zscore();
+  float* host_expected();
+  float* fetch(const float* d_src, size_t n);
+
   size_t* factor;
   size_t pattern_length;
-  void* host_tables = nullptr;  // page-locked slab behind the five table pointers below
-  size_t* pattern_counter;
-  float** pattern_bg_probabilities;
-  float* pattern_logp;
-  float* pattern_zscore;
-  float* expected_counts;
+  size_t* pattern_counter = nullptr;
+  float** pattern_bg_probabilities = nullptr;
+  float* pattern_logp = nullptr;
+  float* pattern_zscore = nullptr;
+  float* expected_counts = nullptr;
   BackgroundModel* background_model;
   size_t number_patterns;
   int max_k;
@@ -94,6 +102,8 @@ class BasePattern {
   pengk_host::DeviceBuffer<uint32_t> d_counts;
   pengk_host::DeviceBuffer<float> d_bgprob;
   pengk_host::DeviceBuffer<float> d_expected;
+  pengk_host::DeviceBuffer<float> d_logp;
+  pengk_host::DeviceBuffer<float> d_z;
 };
 
 class sort_indices {
