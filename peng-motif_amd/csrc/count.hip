@@ -276,7 +276,17 @@ struct KeySplit {
   static constexpr uint32_t LOW = (1u << S) - 1u;
   static constexpr uint32_t NB = 1u << NBITS;
   __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> S) & (NB - 1u); }
-  __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & LOW) | ((id >> (S + NBITS)) << S); }
+  // = (id & LOW) | ((id >> (S + NBITS)) << S), as a bit-field insert: one shift + v_bfi_b32 (the compiler splits
+  // the portable expression into three instructions, and pass A is bound by its VALU instruction count)
+  __host__ __device__ static inline uint32_t payload(uint32_t id) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(LOW), "v"(id), "v"(id >> NBITS));
+    return r;
+#else
+    return (id & LOW) | ((id >> NBITS) & ~LOW);
+#endif
+  }
   __host__ __device__ static inline uint32_t join(uint32_t b, uint32_t p, uint32_t /*outer*/ = 0) {
     return (p & LOW) | (b << S) | ((p >> S) << (S + NBITS));
   }
@@ -320,55 +330,53 @@ __device__ __forceinline__ ScatterShared<NBITS>& scatter_lds() {
   return sh;
 }
 
-// Cross-lane state is kept where the compiler cannot mis-model it: the reservation cursor of bucket
-// b lives in the registers of lane b (read with v_readlane), ring counters are LDS atomics, and ring
-// payloads written by other lanes are read through a volatile pointer.  (A first version kept the
-// cursors in plain LDS words written by lane 0: the compiler legally re-used each lane's stale copy.)
+// No cursor state at all: ring counters are LDS atomics that count every key ever appended to a (wave, bucket),
+// so the counter value a lane gets back IS the key's position in the slice -- the group that completes with slot
+// s goes to slice entries [s - 63, s], an address formed from wave-uniform scalars (SALU) plus lane * 2.  Ring
+// payloads written by other lanes are read with a wavefront-scope atomic load.  (Earlier versions kept a write
+// cursor per bucket in LDS words -- the compiler legally re-used stale copies -- and then in the registers of
+// lane b: three v_readlane, a 64-bit add and two selects per flush, all on the VALU this kernel is bound by.)
 template <class KS, int NBITS>
 struct ScatterEmit {
   static constexpr int NB = 1 << NBITS;
-  static_assert(NB <= 64, "one lane per bucket holds its write cursor");
   static_assert(GROUP == 64, "a group is one 2-byte store per lane");
+  static_assert(2 * NB <= GROUP, "the start offsets 2*b must stay inside the first group");
   typedef __attribute__((address_space(1))) uint16_t global_u16;
   uint16_t* __restrict__ keys;
-  uint32_t slice_cap;  // entries per (wave, bucket) slice, multiple of 64
+  uint32_t slice_cap;  // entries per (wave, bucket) slice, multiple of 64; NB * slice_cap < 2^32
   uint32_t* __restrict__ slice_fill;  // [n_waves][NB] entries written (multiple of 64)
   uint32_t* __restrict__ hist;
-  uint32_t wave, lane, wave_global;
+  uint32_t wave, lane, wave_global;   // wave, wave_global: wave-uniform (readfirstlane'd by the caller)
   uint32_t outer;     // level-1 bucket these keys came from (two-level partition); 0 otherwise
-  // lane b owns the cursor of bucket b: address of its next group and the room left in its slice.  Kept in
-  // registers and read with v_readlane: no 64-bit multiply, no LDS word another lane could see stale.
-  uint64_t my_ptr;
-  uint32_t my_room;
 
-  // wave-major layout region[wave][bucket][slice_cap]: the slices a wave writes to sit within ~1 MiB
-  __device__ __forceinline__ void init_cursors() {
-    const uint32_t b = lane < (uint32_t)NB ? lane : 0u;
-    my_ptr = reinterpret_cast<uint64_t>(keys + ((size_t)wave_global * NB + b) * slice_cap);
-    my_room = slice_cap;
+  // All threads of the workgroup, before the first barrier.  Counter b starts at 2*b, not 0: rings fill at the
+  // same pace, and with a row stride of 256 B equal fill levels would put every lane of the ds_write_b16 on the
+  // same few banks; the offset spreads them one bank apart at no cost per key.  The skipped entries are
+  // KEY_INVALID padding at the head of each slice (the whole ring starts as KEY_INVALID).
+  static __device__ __forceinline__ void init_lds() {
+    ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
+    for (uint32_t i = threadIdx.x; i < 4u * (NB + 1u) * (RING_CAP / 2); i += blockDim.x) (&sh.ring[0][0][0])[i] = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < 4u * (NB + 1u); i += blockDim.x) {
+      const uint32_t b = i % (NB + 1u);
+      (&sh.fill[0][0])[i] = b < (uint32_t)NB ? 2u * b : 0u;
+    }
   }
 
-  // Write the 64 ring entries starting at ring index g0 to the slice as ONE 128-byte line (one 2-byte store
-  // per lane; PARTIAL: entries >= nvalid become KEY_INVALID).  b, g0, nvalid are wave-uniform.  The body is
-  // kept short on purpose: it runs about once per window and every scalar instruction in it costs a full
-  // issue slot (the kernel is issue-bound, SALU included).
+  // Write the 64 ring entries of the group starting at slot g0 (a multiple of 64) to slice entries [g0, g0 + 64)
+  // as ONE 128-byte line (one 2-byte store per lane; PARTIAL: entries >= nvalid become KEY_INVALID).
+  // b, g0, nvalid are wave-uniform.
   template <bool PARTIAL>
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
     const uint16_t* ring16 = reinterpret_cast<const uint16_t*>(&scatter_lds<NBITS>().ring[wave][b][0]);
     uint32_t v = (PENGK_ABLATE & 16) ? lane  // experiment: no LDS read in the flush
-                                     : __hip_atomic_load(&ring16[(g0 + 2u * b + lane) & (RING_CAP - 1)], __ATOMIC_RELAXED,
+                                     : __hip_atomic_load(&ring16[(g0 & (uint32_t)(RING_CAP - 1)) + lane], __ATOMIC_RELAXED,
                                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (PARTIAL && lane >= nvalid) v = KEY_INVALID;
-    const uint32_t room = (uint32_t)__builtin_amdgcn_readlane((int)my_room, b);
-    if (room >= (uint32_t)GROUP) {  // wave-uniform
-      // readlane returns int: widen through uint32_t or the low half sign-extends into the high one
-      const uint64_t ptr = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_ptr >> 32), b) << 32) |
-                           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_ptr, b);
-      if (!(PENGK_ABLATE & 32)) ((global_u16*)ptr)[lane] = (uint16_t)v;  // explicit global address space (a flat store would stall LDS waits)
-      const bool mine = lane == b;
-      my_ptr += mine ? 2ull * GROUP : 0ull;
-      my_room -= mine ? (uint32_t)GROUP : 0u;
-    } else if (!PARTIAL || lane < nvalid) {  // slice full: count these windows directly (rare; skewed inputs)
+    if (g0 + (uint32_t)GROUP <= slice_cap) {  // wave-uniform
+      // explicit global address space (a flat store would stall LDS waits); scalar base + lane * 2
+      global_u16* dst = (global_u16*)(keys + ((size_t)wave_global * NB * slice_cap + (size_t)(b * slice_cap + g0)));
+      if (!(PENGK_ABLATE & 32)) dst[lane] = (uint16_t)v;
+    } else if (v != KEY_INVALID) {  // slice full: count these windows directly (rare; skewed inputs)
       __hip_atomic_fetch_add(&hist[KS::join(b, v, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -377,21 +385,20 @@ struct ScatterEmit {
   // meanwhile: ring write, group-complete check, flush) and then only ISSUES the LDS atomic for the current
   // one, so the atomic's latency is covered by the scan arithmetic of the next window instead of an
   // s_waitcnt right behind it.  (Deferring the flush by one more window was tried and bought nothing.)
+  // Inactive lanes append to the sink bucket NB; its "groups" are never written anywhere.
   uint32_t p_slot = 0, p_b = NB, p_payload = 0;
-  bool p_active = false;
 
   __device__ __forceinline__ void finish_pending() {
     ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
-    // ring position rotated by 2*bucket (= one bank per bucket): all rings fill at the same pace, and with a
-    // row stride of 256 B equal fill levels would put every lane of the ds_write on the same few banks
-    reinterpret_cast<uint16_t*>(&sh.ring[wave][p_b][0])[(p_slot + 2u * p_b) & (RING_CAP - 1)] = (uint16_t)p_payload;
-    unsigned long long trig = __builtin_amdgcn_ballot_w64(p_active && (p_slot & (uint32_t)(GROUP - 1)) == (uint32_t)(GROUP - 1));
+    reinterpret_cast<uint16_t*>(&sh.ring[wave][p_b][0])[p_slot & (uint32_t)(RING_CAP - 1)] = (uint16_t)p_payload;
+    unsigned long long trig = __builtin_amdgcn_ballot_w64((p_slot & (uint32_t)(GROUP - 1)) == (uint32_t)(GROUP - 1));
     if (PENGK_ABLATE & 1) trig = 0;
     while (trig) {  // wave-uniform: a ring just completed a group of 64
       const int src = __builtin_ctzll(trig);
       trig &= trig - 1;
       const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)p_b, src);
       const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)p_slot, src);
+      if (fb == (uint32_t)NB) continue;
       __builtin_amdgcn_wave_barrier();
       flush_group<false>(fb, fs - (uint32_t)(GROUP - 1), (uint32_t)GROUP);
     }
@@ -406,22 +413,25 @@ struct ScatterEmit {
     p_b = active ? KS::bucket(can) : (uint32_t)NB;  // every lane appends; inactive ones to the sink
     if (PENGK_ABLATE & 8) p_b = lane & (uint32_t)(NB - 1);  // experiment: conflict-free counter addresses
     p_payload = KS::payload(can);
-    p_active = active;
     p_slot = atomicAdd(&scatter_lds<NBITS>().fill[wave][p_b], 1u);
   }
 
   // end of kernel: partial groups, then publish how much of each slice is filled
   __device__ __forceinline__ void drain() {
     finish_pending();
-    p_active = false;
     p_b = NB;
+    p_slot = 0;
     __builtin_amdgcn_wave_barrier();
     for (uint32_t b = 0; b < (uint32_t)NB; ++b) {
       const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().fill[wave][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       const uint32_t r = f & (uint32_t)(GROUP - 1);
       if (r) flush_group<true>(b, f & ~(uint32_t)(GROUP - 1), r);
     }
-    if (lane < (uint32_t)NB) slice_fill[(size_t)wave_global * NB + lane] = slice_cap - my_room;
+    if (lane < (uint32_t)NB) {
+      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().fill[wave][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const uint32_t full = (f + (uint32_t)(GROUP - 1)) & ~(uint32_t)(GROUP - 1);
+      slice_fill[(size_t)wave_global * NB + lane] = full < slice_cap ? full : slice_cap;
+    }
   }
 };
 
@@ -434,13 +444,11 @@ __global__ __launch_bounds__(256) void count_scatter_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ defer,
                                                             uint32_t* __restrict__ bg_partials) {
   static_assert(2 * W - NBITS == PAYLOAD_BITS, "payload must be 15 bits");
-  ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
-  for (uint32_t i = threadIdx.x; i < 4u * ((1u << NBITS) + 1u); i += blockDim.x) (&sh.fill[0][0])[i] = 0;
+  ScatterEmit<KeySplit<W, NBITS>, NBITS>::init_lds();
   bg_begin<BG>();
   __syncthreads();
-  ScatterEmit<KeySplit<W, NBITS>, NBITS> e{keys, slice_cap, slice_fill, hist, threadIdx.x >> 6, threadIdx.x & 63u,
-                                           blockIdx.x * 4u + (threadIdx.x >> 6), 0u, 0ull, 0u};
-  e.init_cursors();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  ScatterEmit<KeySplit<W, NBITS>, NBITS> e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * 4u + wave, 0u};
   scan_items<W, BOTH, BG>(words32, items, n_items, ltot, defer, e);
   e.drain();
   bg_end<BG>(bg_partials);
@@ -548,13 +556,11 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ fill1, uint32_t n_slices1,
                                                                 uint32_t bpb1, uint16_t* __restrict__ keys2, uint32_t cap2,
                                                                 uint32_t* __restrict__ fill2, uint32_t* __restrict__ hist) {
-  ScatterShared<4>& sh = scatter_lds<4>();
-  for (uint32_t i = threadIdx.x; i < 4u * 17u; i += blockDim.x) (&sh.fill[0][0])[i] = 0;
+  ScatterEmit<Split12L2, 4>::init_lds();
   __syncthreads();
   const uint32_t b1 = blockIdx.x / bpb1, j = blockIdx.x % bpb1;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  ScatterEmit<Split12L2, 4> e{keys2, cap2, fill2, hist, wave, lane, blockIdx.x * 4u + wave, b1, 0ull, 0u};
-  e.init_cursors();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+  ScatterEmit<Split12L2, 4> e{keys2, cap2, fill2, hist, wave, lane, blockIdx.x * 4u + wave, b1};
   const uint32_t per = (n_slices1 + bpb1 - 1) / bpb1;
   const uint32_t first = j * per, last = min(n_slices1, first + per);
   for (uint32_t s = first + wave; s < last; s += 4) {
@@ -959,7 +965,8 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   uint64_t cap64 = share + share / 2 + 512;  // 1.5x the uniform share: real genomes are not uniform
   if (ctx->key_cap_override) cap64 = ctx->key_cap_override;  // test hook: force slices to overflow
   cap64 = (cap64 + 63) / 64 * 64;
-  if (cap64 >= (1ull << 31)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count (slice of %llu keys)", (unsigned long long)cap64);
+  if (cap64 * NB >= (1ull << 32))  // entry offsets inside a wave's NB slices are 32-bit
+    return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count (slice of %llu keys)", (unsigned long long)cap64);
   const uint32_t slice_cap = (uint32_t)cap64;
   int rc = ensure_scratch(ctx, &ctx->d_keys, &ctx->keys_bytes, (size_t)NB * n_waves * slice_cap * sizeof(uint16_t));
   if (rc) return rc;
@@ -1031,7 +1038,7 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   uint64_t cap2_64 = share2 + share2 / 2 + 512;
   if (ctx->key_cap_override) cap2_64 = ctx->key_cap_override;
   cap2_64 = (cap2_64 + 63) / 64 * 64;
-  if (cap1_64 >= (1ull << 31) || cap2_64 >= (1ull << 31)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
+  if (cap1_64 >= (1ull << 31) || cap2_64 * 16ull >= (1ull << 32)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
   const uint32_t cap1 = (uint32_t)cap1_64, cap2 = (uint32_t)cap2_64;
   const size_t bytes1 = (size_t)n_waves1 * 32u * cap1 * sizeof(uint32_t);
   const size_t bytes2 = (size_t)n_waves2 * 16u * cap2 * sizeof(uint16_t);

@@ -282,12 +282,12 @@ def test_device_bg_count_matches_packer_and_oracle(ctx, golden_dir):
 
 
 @pytest.mark.parametrize("impl", [1, 2])
-@pytest.mark.parametrize("W,M", [(10, 64), (10, 0), (8, 64), (6, 0)])
+@pytest.mark.parametrize("W,M", [(10, 64), (10, 0), (8, 64), (6, 0), (12, 0), (12, 64)])
 def test_fused_bg_count(ctx, golden_dir, W, M, impl):
     """pengk_count_bg: the 3-mer bins collected inside the count scan == the packer's / oracle's counts,
     and the count table is unchanged.  M = 64 splits runs (continuing items must not recount their prologue)."""
-    if impl == 2 and W not in (8, 10):
-        pytest.skip("partitioned count is built for W = 8, 10")
+    if impl == 2 and W not in (8, 10, 12):
+        pytest.skip("partitioned count is built for W = 8, 10, 12")
     codes, offs = po.read_fasta(os.path.join(golden_dir, "MafK.fasta"))
     codes, offs = codes[:offs[600]], offs[:601]
     p = pk.Packed(codes, offs, W, M)
