@@ -42,7 +42,17 @@ struct Geo {
   static constexpr int P = ((3 * W - 3 + 15) / 16) * 16;  // prologue bases in front of a continuing item
   static constexpr uint32_t MASK = (1u << (2 * W)) - 1u;
   static constexpr int TOP = 2 * (W - 1);
+  // main scan: windows ending on bases 0 .. W-2 of a chunk straddle two chunks; a 32-bit view of the pair
+  // at bit offset 2(u0 + 17 - W) holds the windows u0 .. u0 + PER - 1 completely
+  static constexpr int PER = (32 - 2 * W) / 2 + 1;
+  static constexpr int NVIEW = (W - 1 + PER - 1) / PER;
 };
+
+// 16 bases (first base in the low bits) -> their reverse complement, first base in the low bits
+__device__ __forceinline__ uint32_t revcomp16(uint32_t x) {
+  const uint32_t r = __builtin_bitreverse32(x);  // base order reversed, but so are the two bits of every base
+  return ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));
+}
 
 // ---------------------------------------------------------------------------------------------
 // The scan shared by both K1 variants.  `Emit` receives every COUNTED window: emit(can, active).
@@ -125,6 +135,7 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
     uint64_t wi = g0 >> 4;
     const uint32_t shift = 2u * (uint32_t)(g0 & 15u);
     uint32_t lo;
+    uint32_t pchunk = 0;  // the 16 bases in front of base P, aligned (last chunk of either prologue)
 
     if (__any(cont ? 1 : 0)) {
       // full prologue: rebuild the ring of counted windows in front of a continuing item
@@ -136,6 +147,7 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
         ++wi;
         const uint32_t chunk = funnel(hi, lo, shift);
         lo = hi;
+        pchunk = chunk;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           const int b = ch * 16 + u;
@@ -167,6 +179,7 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
       ++wi;
       const uint32_t chunk = funnel(hi, lo, shift);
       lo = hi;
+      pchunk = chunk;
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const uint32_t c = (chunk >> (2 * u)) & 3u;
@@ -185,18 +198,37 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
     // the stream word of the NEXT iteration is requested one iteration ahead: vmcnt retires in order, so a
     // load issued after this iteration's key stores (scatter variant) would wait for all of them
     uint32_t nxt = (0u < nw_scan) ? words32[wi + 1] : 0u;
+    // In the main scan ids are not rolled base by base: the stream is little-endian like the ids, so the id of
+    // the window that ends on base u of this chunk is the bit field [2(u+17-W), +2W) of chunk:pchunk, and its
+    // reverse complement the field [2(15-u), +2W) of revcomp(chunk):revcomp(pchunk) -- one v_bfe each, from the
+    // words themselves or from a few 32-bit views of the straddling part (7 VALU per window -> 3.6; pass A of
+    // the partitioned count is bound by its VALU instruction count).
+    uint32_t rprev = revcomp16(pchunk);
     for (uint32_t t0 = 0; t0 < nw_max; t0 += 16) {
       const uint32_t hi = nxt;
       ++wi;
       nxt = (t0 + 16u < nw_scan) ? words32[wi + 1] : 0u;
       const uint32_t chunk = funnel(hi, lo, shift);
       lo = hi;
+      const uint32_t rchunk = BOTH ? revcomp16(chunk) : 0u;
+      uint32_t view[G::NVIEW], rview[G::NVIEW];
+#pragma unroll
+      for (int j = 0; j < G::NVIEW; ++j) {
+        view[j] = funnel(chunk, pchunk, 2u * (uint32_t)(j * G::PER + 17 - W));
+        rview[j] = BOTH ? funnel(rprev, rchunk, 2u * (uint32_t)(j * G::PER + 17 - W)) : 0u;
+      }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        const uint32_t c = (chunk >> (2 * u)) & 3u;
-        id = (id >> 2) | (c << G::TOP);
-        rc = ((rc << 2) & G::MASK) | (c ^ 3u);
-        const uint32_t can = BOTH ? min(id, rc) : id;
+        uint32_t id_u, rc_u = 0;
+        if (u >= W - 1) {  // the window lies inside this chunk
+          id_u = __builtin_amdgcn_ubfe(chunk, 2u * (uint32_t)(u - (W - 1)), 2u * W);
+          if (BOTH) rc_u = __builtin_amdgcn_ubfe(rchunk, 2u * (uint32_t)(15 - u), 2u * W);
+        } else {
+          const int j = u / G::PER, k = W - 2 - u, jr = k / G::PER;
+          id_u = __builtin_amdgcn_ubfe(view[j], 2u * (uint32_t)(u - j * G::PER), 2u * W);
+          if (BOTH) rc_u = __builtin_amdgcn_ubfe(rview[jr], 2u * (uint32_t)(k - jr * G::PER), 2u * W);
+        }
+        const uint32_t can = BOTH ? min(id_u, rc_u) : id_u;
         // "can equals one of the last W-1 counted ids" as min over xors == 0: VALU only.  (The obvious
         // v_cmp_eq chain costs 8 s_or_b64 per window and the kernel was bound by the CU's single scalar
         // ALU: 42 SALU instructions per window, profiles/r01_v3_pmc_sq.txt.)
@@ -205,9 +237,11 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
         for (int d = 2; d <= W - 1; ++d) diff = min(diff, can ^ ring[(u - d) & 15]);
         const bool match = diff == 0u;
         ring[u] = match ? INVALID_ID : can;
-        bgc.kmer3(id, t0 + (uint32_t)u < nw_all);
+        bgc.kmer3(id_u, t0 + (uint32_t)u < nw_all);
         emit(can, !match && t0 + (uint32_t)u < nw);
       }
+      pchunk = chunk;
+      rprev = rchunk;
     }
   }
 
@@ -362,38 +396,45 @@ struct ScatterEmit {
     }
   }
 
-  // Write the 64 ring entries of the group starting at slot g0 (a multiple of 64) to slice entries [g0, g0 + 64)
-  // as ONE 128-byte line (one 2-byte store per lane; PARTIAL: entries >= nvalid become KEY_INVALID).
-  // b, g0, nvalid are wave-uniform.
+  // A completed group (64 ring entries from slot g0, a multiple of 64) goes to slice entries [g0, g0 + 64) as ONE
+  // 128-byte line, one 2-byte store per lane (PARTIAL: entries >= nvalid become KEY_INVALID).  b, g0 and nvalid
+  // are wave-uniform.  (Splitting this into "read now, store in the next call" and really overlapping the slot
+  // atomic with the next window's scan were both built and measured: no gain -- the kernel is bound by the LDS
+  // pipeline, other waves already cover the latencies.)
+  __device__ __forceinline__ uint32_t read_group(uint32_t b, uint32_t g0) const {
+    typedef const volatile __attribute__((address_space(3))) uint16_t lds_u16;  // a generic pointer would become a flat load
+    lds_u16* ring16 = (lds_u16*)&scatter_lds<NBITS>().ring[wave][b][0];
+    return (PENGK_ABLATE & 16) ? lane  // experiment: no LDS read in the flush
+                               : (uint32_t)ring16[(g0 & (uint32_t)(RING_CAP - 1)) + lane];
+  }
+  __device__ __forceinline__ void store_line(uint32_t off, uint32_t v) const {
+    // explicit global address space (a flat store would stall LDS waits); scalar base + lane * 2
+    global_u16* dst = (global_u16*)(keys + ((size_t)wave_global * NB * slice_cap + (size_t)off));
+    if (!(PENGK_ABLATE & 32)) dst[lane] = (uint16_t)v;
+  }
   template <bool PARTIAL>
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
-    const uint16_t* ring16 = reinterpret_cast<const uint16_t*>(&scatter_lds<NBITS>().ring[wave][b][0]);
-    uint32_t v = (PENGK_ABLATE & 16) ? lane  // experiment: no LDS read in the flush
-                                     : __hip_atomic_load(&ring16[(g0 & (uint32_t)(RING_CAP - 1)) + lane], __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_WAVEFRONT);
+    uint32_t v = read_group(b, g0);
     if (PARTIAL && lane >= nvalid) v = KEY_INVALID;
-    if (g0 + (uint32_t)GROUP <= slice_cap) {  // wave-uniform
-      // explicit global address space (a flat store would stall LDS waits); scalar base + lane * 2
-      global_u16* dst = (global_u16*)(keys + ((size_t)wave_global * NB * slice_cap + (size_t)(b * slice_cap + g0)));
-      if (!(PENGK_ABLATE & 32)) dst[lane] = (uint16_t)v;
-    } else if (v != KEY_INVALID) {  // slice full: count these windows directly (rare; skewed inputs)
+    if (g0 + (uint32_t)GROUP <= slice_cap)  // wave-uniform
+      store_line(b * slice_cap + g0, v);
+    else if (v != KEY_INVALID)  // slice full: count these windows directly (rare; skewed inputs)
       __hip_atomic_fetch_add(&hist[KS::join(b, v, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 
-  // The append is software-pipelined: a call first completes the PREVIOUS key (its ring slot has arrived
-  // meanwhile: ring write, group-complete check, flush) and then only ISSUES the LDS atomic for the current
-  // one, so the atomic's latency is covered by the scan arithmetic of the next window instead of an
-  // s_waitcnt right behind it.  (Deferring the flush by one more window was tried and bought nothing.)
+  // The append is split over two calls: a call first completes the PREVIOUS key (ring write, group-complete
+  // check, flush) and then issues the LDS atomic for the current one.
   // Inactive lanes append to the sink bucket NB; its "groups" are never written anywhere.
   uint32_t p_slot = 0, p_b = NB, p_payload = 0;
 
   __device__ __forceinline__ void finish_pending() {
     ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
-    reinterpret_cast<uint16_t*>(&sh.ring[wave][p_b][0])[p_slot & (uint32_t)(RING_CAP - 1)] = (uint16_t)p_payload;
+    // u16 index (bucket << 7) | (slot & 127) inside the wave's rings: and, shift-or, shift-add
+    static_assert(RING_CAP == 128, "ring rows are 128 u16 entries");
+    reinterpret_cast<uint16_t*>(&sh.ring[wave][0][0])[(p_b << 7) | (p_slot & (uint32_t)(RING_CAP - 1))] = (uint16_t)p_payload;
     unsigned long long trig = __builtin_amdgcn_ballot_w64((p_slot & (uint32_t)(GROUP - 1)) == (uint32_t)(GROUP - 1));
     if (PENGK_ABLATE & 1) trig = 0;
-    while (trig) {  // wave-uniform: a ring just completed a group of 64
+    while (trig) {  // wave-uniform: a ring just completed a group of 64 (on average one per call)
       const int src = __builtin_ctzll(trig);
       trig &= trig - 1;
       const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)p_b, src);
@@ -405,10 +446,8 @@ struct ScatterEmit {
   }
 
   __device__ __forceinline__ void operator()(uint32_t can, bool active) {
-    // keep the scheduler from hoisting the completion of the previous key above this window's scan
-    // arithmetic (it would put the s_waitcnt right behind the atomic again)
-    __builtin_amdgcn_sched_barrier(0);
     if (PENGK_ABLATE & 2) return;
+    __builtin_amdgcn_sched_barrier(0);
     finish_pending();  // (the first call completes a dummy append to the sink bucket)
     p_b = active ? KS::bucket(can) : (uint32_t)NB;  // every lane appends; inactive ones to the sink
     if (PENGK_ABLATE & 8) p_b = lane & (uint32_t)(NB - 1);  // experiment: conflict-free counter addresses
