@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--strand", default="BOTH", choices=["BOTH", "PLUS"])
     ap.add_argument("--pwms", type=int, default=16, help="seed PWMs for the EM phase (whole job)")
     ap.add_argument("--em-iters", type=int, default=10)
+    ap.add_argument("--em-fast", type=int, default=1, help="pengk option em_fast (one reciprocal per k-mer weight)")
     ap.add_argument("--em-stress-pwms", type=int, default=1000,
                     help="BASELINE configs[4]: EM-only stress on this many seed PWMs (split over ranks), timed after the steps; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,6 +88,7 @@ def main():
     lib = pk.lib()
     pk._check(lib.pengk_set_stream(ctx.h, ctx_stream.cuda_stream))  # kernels + collectives share one stream
     ctx.set_option("count_impl", args.count_impl)
+    ctx.set_option("em_fast", args.em_fast)
 
     with torch.cuda.stream(ctx_stream):
         # ---- resident input: this rank's shard of the global synthetic set -------------------------

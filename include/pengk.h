@@ -74,7 +74,7 @@ int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
  * histograms (W = 8, 10, 12); "n_windows_hint" = total windows of the attached items (sizes the key buffer
  * tightly; set it after pengk_set_sequences); "key_cap_override" (test hook) entries per bucket region of the
  * partitioned count, 0 = automatic; "iupac_group_bytes" (test hook) scratch budget for one group of large
- * patterns in pengk_iupac_aggregate, 0 = 1 GiB.  Info: "deferred_items" (of the last pengk_count;
+ * patterns in pengk_iupac_aggregate, 0 = 1 GiB; "em_fast" 1 (default) / 0, see pengk_em.  Info: "deferred_items" (of the last pengk_count;
  * synchronises), "num_cu". */
 int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value);
 int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value_out);
@@ -189,8 +189,12 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
 /* ---- K5: EM over the whole 4^W table (Peng::em_optimize_pwms + calculate_prob_odds,
  *      src/peng.cpp:48-197; row normalisation src/iupac_pattern.cpp:291-303) ----------------------
  * h_pwms: n_pwm x W x 4 floats, updated in place with the PWM the reference's loop ends on (before the
- * extra normalisation of the IUPACPattern(ori, pwm) constructor).  Per-element terms are the
- * reference's float32 expressions; the 4^W-term sums are accumulated in fp64 in a fixed order.
+ * extra normalisation of the IUPACPattern(ori, pwm) constructor).  The float32 product over the PWM columns
+ * is built in the reference's order; the per-k-mer weight c*s / (1 + s/(prod/bg)) is evaluated as
+ * c*s*prod / (prod + s*bg) with one reciprocal (option "em_fast" = 1, the default; ~1 ulp per term) or with the
+ * reference's three float32 divisions (option "em_fast" = 0, term-for-term the reference's bits).  The 4^W-term
+ * sums are accumulated in fp64 in a fixed order in both modes (the reference adds serially in float32, error up
+ * to 2.6e-4 relative), so results agree with the reference within BASELINE.json's 1e-5 relative either way.
  * h_iters / h_change (optional): iterations run and last `change` per PWM. */
 int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturation, float threshold,
              int max_iterations, const uint32_t* d_counts, const float* d_bg, int* h_iters, float* h_change);

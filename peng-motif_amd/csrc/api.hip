@@ -116,6 +116,11 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     ctx->key_cap_override = (uint64_t)value;
     return PENGK_OK;
   }
+  if (strcmp(name, "em_fast") == 0) {
+    if (value < 0 || value > 1) return fail(PENGK_ERR_ARG, "em_fast must be 0 or 1");
+    ctx->em_fast = (int)value;
+    return PENGK_OK;
+  }
   if (strcmp(name, "iupac_group_bytes") == 0) {
     ctx->iupac_group_bytes = (uint64_t)value;
     return PENGK_OK;

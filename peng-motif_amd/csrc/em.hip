@@ -39,7 +39,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // lane 0 holds the sum; fixed tree => deterministic
 }
 
-template <int W, int HIMAX>
+template <int W, int HIMAX, bool FAST>
 __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
                                                             const uint32_t* __restrict__ counts,
                                                             const float* __restrict__ bg, float saturation,
@@ -71,9 +71,18 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
   double S = 0.0;
 
   auto leaf = [&](uint32_t x, float prod) -> double {
-    const float odds = prod / bg[x];
-    const float w = ((float)counts[x] * saturation) / (1 + saturation / odds);  // src/peng.cpp:124-125
-    return (double)w;
+    if constexpr (FAST) {
+      // c*s / (1 + s/(prod/bg)) == c*s*prod / (prod + s*bg): one reciprocal (v_rcp_f32 + one Newton step, ~1 ulp)
+      // instead of three IEEE divisions (33 of the 42 VALU instructions of a leaf).  Same limits: prod = 0 -> 0.
+      const float den = fmaf(saturation, bg[x], prod);
+      float r = __builtin_amdgcn_rcpf(den);
+      r = fmaf(fmaf(-den, r, 1.0f), r, r);
+      return (double)(((float)counts[x] * saturation) * prod * r);
+    } else {
+      const float odds = prod / bg[x];
+      const float w = ((float)counts[x] * saturation) / (1 + saturation / odds);  // src/peng.cpp:124-125
+      return (double)w;
+    }
   };
 
   if constexpr (G::HI == 0) {
@@ -96,9 +105,12 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
     }
   } else {
     static_assert(G::HI == 4 || G::HI == 0 || G::HI == 2, "EM geometry");
+    // the two outer digits stay loops: unrolled 256 leaves deep the kernel needs > 256 VGPRs (one wave per SIMD)
+#pragma unroll 1
     for (int d0 = 0; d0 < 4; ++d0) {
       const float p0 = pr * s_pwm[(G::PB + 0) * 4 + d0];
       double s0 = 0.0;
+#pragma unroll 1
       for (int d1 = 0; d1 < 4; ++d1) {
         const float p1 = p0 * s_pwm[(G::PB + 1) * 4 + d1];
         double s1 = 0.0;
@@ -207,7 +219,7 @@ __global__ void em_init_kernel(int n, int W, float threshold, int max_it, int32_
   change[i] = c0;
 }
 
-template <int W, int HIMAX>
+template <int W, int HIMAX, bool FAST>
 int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
                const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
   using G = EmGeo<W, HIMAX>;
@@ -225,7 +237,7 @@ int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, f
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
     for (int it = 0; it < max_it; ++it) {
-      hipLaunchKernelGGL((em_accumulate_kernel<W, HIMAX>), dim3(G::NB, (unsigned)nb), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL((em_accumulate_kernel<W, HIMAX, FAST>), dim3(G::NB, (unsigned)nb), dim3(256), 0, ctx->stream,
                          d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_partials);
       hipLaunchKernelGGL((em_finalize_kernel<W, HIMAX>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
                          d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it);
@@ -239,12 +251,15 @@ template <int W>
 int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
              const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
   // few PWMs: more, smaller workgroups so that every CU gets several waves
+  const bool fast = ctx->em_fast != 0;
   if constexpr (W >= 8) {
     const int64_t wg4 = n_pwm * EmGeo<W, 4>::NB;
     if (wg4 < (int64_t)ctx->num_cu * 8)
-      return launch_geo<W, 2>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
+      return fast ? launch_geo<W, 2, true>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change)
+                  : launch_geo<W, 2, false>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
   }
-  return launch_geo<W, 4>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
+  return fast ? launch_geo<W, 4, true>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change)
+              : launch_geo<W, 4, false>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
 }
 
 }  // namespace

@@ -44,6 +44,13 @@ pengk_ctx* context() {
     }
   }
   if (!g_ctx) check(pengk_create(Global::device, &g_ctx), "pengk_create");
+  static bool options_set = false;
+  if (!options_set) {
+    options_set = true;
+    // PENGK_EM_FAST=0: the reference's three float divisions per k-mer weight in the EM instead of one reciprocal
+    // (the default; results agree within 1e-5 relative, see include/pengk.h)
+    if (const char* e = std::getenv("PENGK_EM_FAST")) check(pengk_set_option(g_ctx, "em_fast", std::atoi(e) ? 1 : 0), "pengk_set_option");
+  }
   return g_ctx;
 }
 

@@ -408,19 +408,29 @@ def test_em_against_oracle_and_reference(ctx, golden_dir, name):
 
 
 def test_em_single_iteration_accumulators(ctx, golden_dir):
-    """One EM step with threshold 0 / max_iter 1: normalised rows equal the oracle's fp64 accumulation."""
+    """One EM step with threshold 0 / max_iter 1 against the oracle's fp64 accumulation of the reference's float32
+    weights: em_fast = 0 (the reference's three divisions per weight) reproduces the normalised rows to 2 ulp;
+    the default em_fast = 1 (one reciprocal per weight) to BASELINE.json's 1e-5 relative."""
     r = cpu_pipeline(golden_dir, "mafk100_w8_both")
     g = r["g"]
     W, K = r["W"], r["K"]
     d = gpu_tables(ctx, r)
     bg_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K])
-    pw, iters, _ = ctx.em(W, g["pwm_pre"], d["counts"], bg_k, 1e4, 0.0, 1)
-    for i in range(len(g["pwm_ids"])):
-        acc = po.em_accumulate(W, r["counts"], r["bgp"][K], g["pwm_pre"][i])
-        want = acc.astype(np.float32)
-        want = want / want.sum(axis=1, keepdims=True, dtype=np.float32)
-        assert iters[i] == 1
-        assert ulp_diff(pw[i], want) <= 2
+    for fast in (1, 0):
+        ctx.set_option("em_fast", fast)
+        try:
+            pw, iters, _ = ctx.em(W, g["pwm_pre"], d["counts"], bg_k, 1e4, 0.0, 1)
+        finally:
+            ctx.set_option("em_fast", 1)
+        for i in range(len(g["pwm_ids"])):
+            acc = po.em_accumulate(W, r["counts"], r["bgp"][K], g["pwm_pre"][i])
+            want = acc.astype(np.float32)
+            want = want / want.sum(axis=1, keepdims=True, dtype=np.float32)
+            assert iters[i] == 1
+            if fast:
+                assert (np.abs(pw[i].astype(np.float64) - want) <= 1e-5 * np.abs(want)).all()
+            else:
+                assert ulp_diff(pw[i], want) <= 2
 
 
 def test_em_many_pwms_batch(ctx, golden_dir):
@@ -478,3 +488,27 @@ def test_iupac_many_large_patterns_in_one_call(ctx, both):
                 b = np.float32(getattr(w, f)).view(np.uint32)
                 assert a == b, (budget, j, f, po.iupac_str(int(ids[j]), W))
     ctx.set_option("iupac_group_bytes", 0)
+
+
+def test_em_fast_mode_within_stated_tolerance(ctx, golden_dir):
+    """Option em_fast = 1 (the default) replaces the three IEEE divisions of a k-mer weight by one reciprocal.  BASELINE.json's bar for EM
+    results is 1e-5 relative: the PWMs after 10 iterations must agree with the exact mode (and so with the oracle) to that,
+    with the same iteration counts on the golden cases."""
+    for name in ("mafk_w10_both", "mafk100_w8_plus"):
+        r = cpu_pipeline(golden_dir, name)
+        g = r["g"]
+        W, K = r["W"], r["K"]
+        if len(g["pwm_ids"]) == 0:
+            continue
+        d = gpu_tables(ctx, r)
+        bg_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K])
+        fast, it1, ch1 = ctx.em(W, g["pwm_pre"], d["counts"], bg_k, 1e4, 0.08, 10)
+        ctx.set_option("em_fast", 0)
+        try:
+            exact, it0, ch0 = ctx.em(W, g["pwm_pre"], d["counts"], bg_k, 1e4, 0.08, 10)
+        finally:
+            ctx.set_option("em_fast", 1)
+        assert np.array_equal(it0, it1)
+        rel = np.abs(fast.astype(np.float64) - exact) / np.maximum(np.abs(exact), 1e-30)
+        assert rel.max() <= 1e-5, rel.max()
+        assert np.abs(ch1 - ch0).max() <= 1e-5
