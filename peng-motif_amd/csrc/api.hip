@@ -89,6 +89,7 @@ int pengk_destroy(pengk_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_defer) (void)hipFree(ctx->d_defer);
   if (ctx->d_em_partials) (void)hipFree(ctx->d_em_partials);
+  if (ctx->d_em_tables) (void)hipFree(ctx->d_em_tables);
   if (ctx->d_misc) (void)hipFree(ctx->d_misc);
   if (ctx->d_keys) (void)hipFree(ctx->d_keys);
   if (ctx->d_iupac_big) (void)hipFree(ctx->d_iupac_big);

@@ -39,6 +39,17 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // lane 0 holds the sum; fixed tree => deterministic
 }
 
+// fast mode: the two per-k-mer factors that do not depend on the PWM, once per call instead of once per PWM and iteration
+__global__ __launch_bounds__(256) void em_prepare_kernel(const uint32_t* __restrict__ counts, const float* __restrict__ bg,
+                                                         float saturation, uint32_t np, float* __restrict__ cs,
+                                                         float* __restrict__ sb) {
+  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
+    cs[x] = (float)counts[x] * saturation;
+    sb[x] = saturation * bg[x];
+  }
+}
+
+// FAST: `counts` / `bg` are reinterpreted as the float tables of em_prepare_kernel (cs, sb)
 template <int W, int HIMAX, bool FAST>
 __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
                                                             const uint32_t* __restrict__ counts,
@@ -49,7 +60,6 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
   if (state[2 * pw + 1] == 0) return;  // converged or out of iterations (block-uniform)
 
   __shared__ float s_pwm[W * 4];
-  __shared__ double s_S[256];
   __shared__ double s_red[4][G::HI > 0 ? G::HI * 4 : 1];
   if (threadIdx.x < W * 4) s_pwm[threadIdx.x] = pwms[(size_t)pw * W * 4 + threadIdx.x];
   __syncthreads();
@@ -72,12 +82,12 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 
   auto leaf = [&](uint32_t x, float prod) -> double {
     if constexpr (FAST) {
-      // c*s / (1 + s/(prod/bg)) == c*s*prod / (prod + s*bg): one reciprocal (v_rcp_f32 + one Newton step, ~1 ulp)
-      // instead of three IEEE divisions (33 of the 42 VALU instructions of a leaf).  Same limits: prod = 0 -> 0.
-      const float den = fmaf(saturation, bg[x], prod);
-      float r = __builtin_amdgcn_rcpf(den);
-      r = fmaf(fmaf(-den, r, 1.0f), r, r);
-      return (double)(((float)counts[x] * saturation) * prod * r);
+      // c*s / (1 + s/(prod/bg)) == c*s*prod / (prod + s*bg): one reciprocal (v_rcp_f32, 1 ulp) instead of three
+      // IEEE divisions (33 of the 42 VALU instructions of a leaf); c*s and s*bg come precomputed.
+      // Same limits: prod = 0 -> 0.
+      const float cs = __builtin_bit_cast(float, counts[x]);
+      const float den = bg[x] + prod;
+      return (double)(cs * prod * __builtin_amdgcn_rcpf(den));
     } else {
       const float odds = prod / bg[x];
       const float w = ((float)counts[x] * saturation) / (1 + saturation / odds);  // src/peng.cpp:124-125
@@ -138,9 +148,28 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
     }
   }
 
-  // ---- block reduction (fixed order) ------------------------------------------------------------
-  s_S[tid] = S;
+  // ---- block reduction (fixed tree) --------------------------------------------------------------
+  // Digits 0..2 of the pattern id are lane bits, digit 3 is the wave index.  Cell (p, a) for p < 3 is the sum of
+  // S over the lanes whose digit p equals a: an xor butterfly over the four lane bits outside digit p leaves it
+  // in every lane of the class; lane a << 2p publishes it.  (A serial pass over 256 LDS values per cell was most
+  // of the kernel for small PWM batches.)
   const int wave = tid >> 6, lane = tid & 63;
+  __shared__ double s_cls[4][3][4];
+  __shared__ double s_T[4];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    double v = S;
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+      if ((b >> 1) != p) v += __shfl_xor(v, 1 << b, 64);
+    if ((lane & ~(3 << (2 * p))) == 0) s_cls[wave][p][(lane >> (2 * p)) & 3] = v;
+    if (p == 0) {  // whole wave
+      double t = v;
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      if (lane == 0) s_T[wave] = t;
+    }
+  }
   if constexpr (G::HI > 0) {
 #pragma unroll
     for (int h = 0; h < G::HI; ++h)
@@ -155,12 +184,12 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
   if (tid < (uint32_t)G::CELLS) {
     const int p = tid >> 2, a = tid & 3;
     double v = 0.0;
-    if (p < G::LO) {  // digit comes from the thread index: sum the threads whose digit p equals a
-      for (int t = 0; t < 256; ++t)
-        if (((t >> (2 * p)) & 3) == a) v += s_S[t];
+    if (p < 3) {
+      v = ((s_cls[0][p][a] + s_cls[1][p][a]) + s_cls[2][p][a]) + s_cls[3][p][a];
+    } else if (p == 3) {
+      v = s_T[a];
     } else if (p < G::PB) {  // digit fixed by the block index
-      if ((int)((mid >> (2 * (p - G::LO))) & 3u) == a)
-        for (int t = 0; t < 256; ++t) v += s_S[t];
+      if ((int)((mid >> (2 * (p - G::LO))) & 3u) == a) v = ((s_T[0] + s_T[1]) + s_T[2]) + s_T[3];
     } else {
       if constexpr (G::HI > 0) {
         const int h = p - G::PB;
@@ -234,6 +263,18 @@ int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, f
   if (batch > 65535) batch = 65535;  // gridDim.y
   int rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, (size_t)batch * per_pwm);
   if (rc) return rc;
+  if (FAST) {
+    const uint32_t np = 1u << (2 * W);
+    rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, (size_t)2 * np * sizeof(float));
+    if (rc) return rc;
+    float* cs = ctx->d_em_tables;
+    float* sb = cs + np;
+    const unsigned pb = (np + 255) / 256 < 4096u ? (np + 255) / 256 : 4096u;
+    hipLaunchKernelGGL(em_prepare_kernel, dim3(pb), dim3(256), 0, ctx->stream, d_counts, d_bg, saturation, np, cs, sb);
+    PENGK_HIP(hipGetLastError());
+    d_counts = reinterpret_cast<const uint32_t*>(cs);
+    d_bg = sb;
+  }
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
     for (int it = 0; it < max_it; ++it) {

@@ -24,6 +24,8 @@ struct pengk_ctx {
   uint64_t defer_cap = 0;
   double* d_em_partials = nullptr;
   size_t em_partials_bytes = 0;
+  float* d_em_tables = nullptr;  // K5 fast mode: count*saturation | saturation*background, 4^W floats each
+  size_t em_tables_bytes = 0;
   void* d_misc = nullptr;  // small staging buffer
   size_t misc_bytes = 0;
   void* d_bg_partials = nullptr;  // fused K1b: per-block bins
