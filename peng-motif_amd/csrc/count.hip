@@ -509,50 +509,52 @@ __device__ __forceinline__ Scatter32Shared& scatter32_lds() {
   return sh;
 }
 
+// Same cursor-free scheme as ScatterEmit: the ring counter's return value is the key's position in the slice.
+// Counter b starts at b (bank spread; < GROUP32), the skipped entries are KEY32_INVALID padding.
 struct Scatter32Emit {
+  typedef __attribute__((address_space(1))) uint32_t global_u32;
   uint32_t* __restrict__ keys;
-  uint32_t slice_cap;  // entries per (wave, bucket1) slice, multiple of GROUP32
+  uint32_t slice_cap;  // entries per (wave, bucket1) slice, multiple of GROUP32; 32 * slice_cap < 2^32
   uint32_t* __restrict__ slice_fill;
   uint32_t* __restrict__ hist;
-  uint32_t wave, lane, wave_global;
-  uint32_t my_pos, my_base_lo, my_base_hi;
+  uint32_t wave, lane, wave_global;  // wave, wave_global: wave-uniform
 
-  __device__ __forceinline__ void init_cursors() {
-    const uint32_t b = lane < 32u ? lane : 0u;
-    const uint64_t base = reinterpret_cast<uint64_t>(keys + ((size_t)wave_global * 32u + b) * slice_cap);
-    my_base_lo = (uint32_t)base;
-    my_base_hi = (uint32_t)(base >> 32);
-    my_pos = 0;
+  static __device__ __forceinline__ void init_lds() {
+    Scatter32Shared& sh = scatter32_lds();
+    for (uint32_t i = threadIdx.x; i < 4u * 33u * RING32_CAP; i += blockDim.x) (&sh.ring[0][0][0])[i] = KEY32_INVALID;
+    for (uint32_t i = threadIdx.x; i < 4u * 33u; i += blockDim.x) {
+      const uint32_t b = i % 33u;
+      (&sh.fill[0][0])[i] = b < 32u ? b : 0u;
+    }
   }
 
+  // group of 32 ring entries from slot g0 (a multiple of 32) -> slice entries [g0, g0 + 32): one 128-byte line
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
-    const uint32_t pos = __builtin_amdgcn_readlane(my_pos, b);
-    uint32_t v = __hip_atomic_load(&scatter32_lds().ring[wave][b][(g0 + (lane & 31u)) & (RING32_CAP - 1)], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+    typedef const volatile __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* ring = (lds_u32*)&scatter32_lds().ring[wave][b][0];
+    uint32_t v = ring[(g0 & (uint32_t)(RING32_CAP - 1)) + (lane & 31u)];
     if ((lane & 31u) >= nvalid) v = KEY32_INVALID;
-    if (pos + (uint32_t)GROUP32 <= slice_cap) {
-      const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_base_hi, b) << 32) |
-                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_base_lo, b);
-      typedef __attribute__((address_space(1))) uint32_t global_u32;
-      global_u32* dst = (global_u32*)(base + 4ull * pos);
+    if (g0 + (uint32_t)GROUP32 <= slice_cap) {  // wave-uniform
+      global_u32* dst = (global_u32*)(keys + ((size_t)wave_global * 32u * slice_cap + (size_t)(b * slice_cap + g0)));
       if (lane < 32u) dst[lane] = v;
-      if (lane == b) my_pos = pos + (uint32_t)GROUP32;
     } else if (lane < 32u && v != KEY32_INVALID) {  // slice full: count directly
       __hip_atomic_fetch_add(&hist[Split12L1::join(b, v)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
   __device__ __forceinline__ void operator()(uint32_t can, bool active) {
-    const uint32_t b = active ? Split12L1::bucket(can) : 32u;
+    const uint32_t b = active ? Split12L1::bucket(can) : 32u;  // inactive lanes: sink bucket, never flushed
     Scatter32Shared& sh = scatter32_lds();
     const uint32_t slot = atomicAdd(&sh.fill[wave][b], 1u);
-    sh.ring[wave][b][slot & (RING32_CAP - 1)] = Split12L1::payload(can);
-    unsigned long long trig = __builtin_amdgcn_ballot_w64(active && (slot & (uint32_t)(GROUP32 - 1)) == (uint32_t)(GROUP32 - 1));
+    (&sh.ring[wave][0][0])[(b << 6) | (slot & (uint32_t)(RING32_CAP - 1))] = Split12L1::payload(can);
+    static_assert(RING32_CAP == 64, "ring rows are 64 entries");
+    unsigned long long trig = __builtin_amdgcn_ballot_w64((slot & (uint32_t)(GROUP32 - 1)) == (uint32_t)(GROUP32 - 1));
     while (trig) {
-      const int src = __ffsll((long long)trig) - 1;
+      const int src = __builtin_ctzll(trig);
       trig &= trig - 1;
-      const uint32_t fb = __builtin_amdgcn_readlane(b, src);
-      const uint32_t fs = __builtin_amdgcn_readlane(slot, src);
+      const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
+      const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)slot, src);
+      if (fb == 32u) continue;
       __builtin_amdgcn_wave_barrier();
       flush_group(fb, fs - (uint32_t)(GROUP32 - 1), (uint32_t)GROUP32);
     }
@@ -565,7 +567,11 @@ struct Scatter32Emit {
       const uint32_t r = f & (uint32_t)(GROUP32 - 1);
       if (r) flush_group(b, f & ~(uint32_t)(GROUP32 - 1), r);
     }
-    if (lane < 32u) slice_fill[(size_t)wave_global * 32u + lane] = my_pos;
+    if (lane < 32u) {
+      const uint32_t f = __hip_atomic_load(&scatter32_lds().fill[wave][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const uint32_t full = (f + (uint32_t)(GROUP32 - 1)) & ~(uint32_t)(GROUP32 - 1);
+      slice_fill[(size_t)wave_global * 32u + lane] = full < slice_cap ? full : slice_cap;
+    }
   }
 };
 
@@ -576,13 +582,11 @@ __global__ __launch_bounds__(256) void count_scatter12_kernel(const uint32_t* __
                                                               uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
                                                               unsigned long long* __restrict__ ltot,
                                                               uint32_t* __restrict__ defer, uint32_t* __restrict__ bg_partials) {
-  Scatter32Shared& sh = scatter32_lds();
-  for (uint32_t i = threadIdx.x; i < 4u * 33u; i += blockDim.x) (&sh.fill[0][0])[i] = 0;
+  Scatter32Emit::init_lds();
   bg_begin<BG>();
   __syncthreads();
-  Scatter32Emit e{keys, slice_cap, slice_fill, hist, threadIdx.x >> 6, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6),
-                  0u, 0u, 0u};
-  e.init_cursors();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  Scatter32Emit e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * 4u + wave};
   scan_items<12, BOTH, BG>(words32, items, n_items, ltot, defer, e);
   e.drain();
   bg_end<BG>(bg_partials);
@@ -1077,7 +1081,7 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   uint64_t cap2_64 = share2 + share2 / 2 + 512;
   if (ctx->key_cap_override) cap2_64 = ctx->key_cap_override;
   cap2_64 = (cap2_64 + 63) / 64 * 64;
-  if (cap1_64 >= (1ull << 31) || cap2_64 * 16ull >= (1ull << 32)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
+  if (cap1_64 * 32ull >= (1ull << 32) || cap2_64 * 16ull >= (1ull << 32)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
   const uint32_t cap1 = (uint32_t)cap1_64, cap2 = (uint32_t)cap2_64;
   const size_t bytes1 = (size_t)n_waves1 * 32u * cap1 * sizeof(uint32_t);
   const size_t bytes2 = (size_t)n_waves2 * 16u * cap2 * sizeof(uint16_t);
