@@ -637,13 +637,21 @@ __global__ __launch_bounds__(1024) void count_hist_kernel(const uint16_t* __rest
   for (uint32_t s = first + wave; s < last; s += 16) {
     const uint32_t n8 = slice_fill[(size_t)s * nb + b] >> 3;  // groups of 8 keys (16 B); fill is a multiple of 64
     const uint4* src = reinterpret_cast<const uint4*>(keys + ((size_t)s * nb + b) * slice_cap);
-    for (uint32_t i = lane; i < n8; i += 64) {
-      const uint4 v = src[i];
+    auto count8 = [&](const uint4& v) {
       const uint32_t k[8] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16, v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         if (k[q] < (1u << PAYLOAD_BITS)) atomicAdd(&h[k[q]], 1u);
+    };
+    uint32_t i = lane;
+    for (; i + 448 < n8; i += 512) {  // eight 16-byte loads in flight per lane before their 64 LDS adds
+      uint4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[i + 64 * q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) count8(v[q]);
     }
+    for (; i < n8; i += 64) count8(src[i]);
   }
   __syncthreads();
   uint32_t* dst = temp + ((size_t)f << PAYLOAD_BITS);
