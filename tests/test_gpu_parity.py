@@ -514,19 +514,20 @@ def test_em_fast_mode_within_stated_tolerance(ctx, golden_dir):
         assert np.abs(ch1 - ch0).max() <= 1e-5
 
 
-def test_em_large_batch_geometry_against_oracle(ctx, golden_dir):
-    """160 PWMs at W = 10 select the 256-leaves-per-thread geometry (the one BASELINE configs[4] runs on); both weight
+@pytest.mark.parametrize("n_pwm", [160, 513])
+def test_em_large_batch_geometry_against_oracle(ctx, golden_dir, n_pwm):
+    """160 and 513 PWMs at W = 10 select the 256-leaves-per-thread geometry (the one BASELINE configs[4] runs on); both weight
     modes against the oracle's fp64-accumulating EM, 2 iterations, for a sample of the PWMs (1e-5 relative, the stated bar)."""
     r = cpu_pipeline(golden_dir, "mafk_w10_plus")
     W, K = r["W"], r["K"]
     d = gpu_tables(ctx, r)
     bg_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K])
-    order = np.lexsort((np.arange(4 ** W), -r["counts"].astype(np.int64)))[:160]
+    order = np.lexsort((np.arange(4 ** W), -r["counts"].astype(np.int64)))[:n_pwm]
     pwms = np.full((len(order), W, 4), 0.1, np.float32)
     for i, x in enumerate(order):
         for p_ in range(W):
             pwms[i, p_, (int(x) >> (2 * p_)) & 3] = 0.7
-    want = {i: po.em(W, r["counts"], r["bgp"][K], pwms[i], 1e4, 0.0, 2, mode=1, final_norm=False)[0] for i in (0, 57, 159)}
+    want = {i: po.em(W, r["counts"], r["bgp"][K], pwms[i], 1e4, 0.0, 2, mode=1, final_norm=False)[0] for i in (0, 57, n_pwm - 2, n_pwm - 1)}
     for fast in (1, 0):
         ctx.set_option("em_fast", fast)
         try:
