@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--strand", default="BOTH", choices=["BOTH", "PLUS"])
     ap.add_argument("--pwms", type=int, default=16, help="seed PWMs for the EM phase (whole job)")
     ap.add_argument("--em-iters", type=int, default=10)
+    ap.add_argument("--k4-patterns", type=int, default=2000,
+                    help="K4 probe after the timed steps: degenerate IUPAC patterns of one hill-climb round (0 = off)")
     ap.add_argument("--em-fast", type=int, default=1, help="pengk option em_fast (one reciprocal per k-mer weight)")
     ap.add_argument("--em-stress-pwms", type=int, default=1000,
                     help="BASELINE configs[4]: EM-only stress on this many seed PWMs (split over ranks), timed after the steps; 0 = skip")
@@ -198,6 +200,31 @@ def main():
                 best = ms if best is None else min(best, ms)
             em_stress = (n_st, best)
 
+        # ---- K4 probe (not part of the step): the mutants of one hill-climb round, 1 .. 6 degenerate letters each ----
+        k4 = None
+        if args.k4_patterns > 0:
+            rk = np.random.default_rng(7)
+            sizes = np.array([1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 4])
+            ids, members = [], 0
+            for _ in range(args.k4_patterns):
+                x = int(rk.integers(0, NP))
+                letters = [(x >> (2 * q)) & 3 for q in range(W)]
+                for q in rk.choice(W, size=int(rk.integers(1, 7)), replace=False):
+                    letters[q] = int(rk.integers(4, 11))
+                ids.append(sum(l * 11 ** q for q, l in enumerate(letters)))
+                members += int(np.prod(sizes[letters]))
+            ids = np.array(ids, dtype=np.uint64)
+            st = np.zeros(len(ids) * 24, np.uint8)
+            best = None
+            for rep in range(3):
+                ctx.synchronize()
+                t_k = time.perf_counter()
+                pk._check(lib.pengk_iupac_aggregate(ctx.h, W, int(both), ids.ctypes.data, len(ids), counts.data_ptr(),
+                                                    bgprob[K].data_ptr(), expected.data_ptr(), st.ctypes.data))
+                d_k = time.perf_counter() - t_k
+                best = d_k if best is None else min(best, d_k)
+            k4 = (len(ids), members, best)
+
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -232,9 +259,14 @@ def main():
                 "em_stress_ms": round(em_stress[1], 4) if em_stress else None,
                 "em_stress_evals_per_s_per_gpu": round(em_stress[0] * args.em_iters * NP / (em_stress[1] * 1e-3), 1)
                 if em_stress and em_stress[1] else None,
+                # K4 (host call incl. id upload, result download and the libm epilogue): patterns and underlying k-mers
+                "k4_patterns": k4[0] if k4 else None, "k4_ms": round(k4[2] * 1e3, 4) if k4 else None,
+                "k4_kmers_visited_per_s": round(k4[1] / k4[2], 1) if k4 else None,
             },
             "roofline": {"kernel": "pengk_count_bg = count_scatter_kernel<%d,%s> + count_hist_kernel + count_gather_kernel (K1, K1b fused)"
                                    % (W, "both" if both else "plus") if W in (8, 10) and args.count_impl != 1
+                                   else "pengk_count_bg = count_scatter12_kernel<%s> + count_rescatter12_kernel + count_hist_kernel + count_gather12_kernel (K1 two-level, K1b fused)"
+                                   % ("both" if both else "plus") if W == 12 and args.count_impl != 1
                                    else "pengk_count_bg = count_kernel<%d,%s> (direct atomics)" % (W, "both" if both else "plus"),
                          "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
