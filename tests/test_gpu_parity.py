@@ -537,3 +537,60 @@ def test_em_large_batch_geometry_against_oracle(ctx, golden_dir, n_pwm):
         assert (iters == 2).all()
         for i, p1 in want.items():
             assert (np.abs(pw[i].astype(np.float64) - p1) <= 1e-5 * np.abs(p1)).all(), (fast, i)
+
+
+@pytest.mark.parametrize("W,both", [(4, True), (4, False), (12, True), (12, False)])
+def test_all_kernels_at_the_ends_of_the_length_range(ctx, W, both):
+    """The golden cases cover W = 6, 8, 10.  W = 4 (tables smaller than a workgroup, K = 2 < W - 1 barely) and W = 12
+    (two-level count, 2^24 patterns) go through every kernel here against the oracle on a synthetic set: count + sweep
+    bit-exact (log-p 1 ulp), IUPAC sums bit-exact, one EM iteration within 1e-5 relative."""
+    K = min(W - 1, 2)
+    codes, offs = po.synth(5, 0, 3000, 150)
+    codes = codes.copy()
+    codes[::997] = 0  # some invalid bases: runs, the N rule
+    n = po.bg_counts(codes, offs, 2)
+    V = po.bg_V(n, 2)
+    counts, ltot = po.count(codes, offs, W, both)
+    bgp = [po.bgprob(W, k, V, both) for k in range(K + 1)]
+    e, lp, z = po.stats(W, counts, bgp[K], ltot)
+    r = dict(W=W, both=both, K=K, codes=codes, offs=offs)
+    d = gpu_tables(ctx, r)
+    assert int(d["ltot"].to_host()[0]) == ltot
+    assert bits_equal(d["counts"].to_host().astype(np.uint64), counts)
+    got_bgp = d["bgprob"].to_host()
+    for k in range(K + 1):
+        assert bits_equal(got_bgp[k], bgp[k]), "bgp%d" % k
+    assert bits_equal(d["expected"].to_host(), e)
+    assert bits_equal(d["z"].to_host(), z)
+    assert ulp_diff(d["logp"].to_host(), lp) <= 1
+    # K4: a few degenerate patterns around the most frequent k-mer, small and large
+    top = int(np.argmax(counts))
+    base = [(top >> (2 * q)) & 3 for q in range(W)]
+    ids = []
+    for deg in ([0], [1, 2], list(range(W // 2)), list(range(W - 1)), list(range(W))):
+        ls = list(base)
+        for q in deg:
+            ls[q] = 10 if q % 2 == 0 else 4 + (q % 6)
+        ids.append(sum(l * 11 ** q for q, l in enumerate(ls)))
+    ids = np.array(ids, dtype=np.uint64)
+    bgp_k = pk.DeviceArray.from_host(ctx, bgp[K])
+    out = ctx.iupac_aggregate(W, both, ids, d["counts"], bgp_k, d["expected"])
+    for j, i in enumerate(ids):
+        w = po.iupac_aggregate(int(i), W, both, counts, bgp[K], e)
+        assert int(out["sites"][j]) == w.sites
+        for f in ("bg_p", "expected", "zscore", "log_pvalue"):
+            assert np.float32(out[f][j]).view(np.uint32) == np.float32(getattr(w, f)).view(np.uint32), (f, po.iupac_str(int(i), W))
+    # K5: one iteration from a seed PWM
+    pwm = np.full((1, W, 4), 0.1, np.float32)
+    for q in range(W):
+        pwm[0, q, base[q]] = 0.7
+    for fast in (1, 0):
+        ctx.set_option("em_fast", fast)
+        try:
+            pw, iters, _ = ctx.em(W, pwm, d["counts"], bgp_k, 1e4, 0.0, 1)
+        finally:
+            ctx.set_option("em_fast", 1)
+        acc = po.em_accumulate(W, counts, bgp[K], pwm[0])
+        want = acc / acc.sum(axis=1, keepdims=True)
+        assert iters[0] == 1
+        assert (np.abs(pw[0].astype(np.float64) - want) <= 1e-5 * np.abs(want)).all(), fast
