@@ -21,8 +21,9 @@ namespace pengk {
 namespace {
 
 // HIMAX = 4: 256 leaves per thread (fewest partial products; best when the grid is full anyway).
-// HIMAX = 2: 16 leaves per thread, 16x more workgroups -- for small PWM batches that would otherwise leave
-// most CUs with a single wave (the 16-PWM batch of a typical run).
+// HIMAX = 3 / 2: 64 / 16 leaves per thread, 4x / 16x more workgroups -- for small PWM batches that would
+// otherwise leave most CUs with a single wave (the 16-PWM batch of a typical run takes HIMAX = 3 at W = 10:
+// 1024 workgroups, four per CU, and a fourth of the per-workgroup reductions of HIMAX = 2).
 template <int W, int HIMAX = 4>
 struct EmGeo {
   static constexpr int LO = 4;                               // digits taken from threadIdx (256 threads)
@@ -126,101 +127,77 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 
   if constexpr (G::HI == 0) {
     leaf(xlow, pr, S);
-  } else if constexpr (G::HI == 2) {
-#pragma unroll
-    for (int d0 = 0; d0 < 4; ++d0) {
-      float p0[P];
-      double s0[P];
-#pragma unroll
-      for (int q = 0; q < P; ++q) {
-        p0[q] = pr[q] * s_pwm[q][(G::PB + 0) * 4 + d0];
-        s0[q] = 0.0;
-      }
-#pragma unroll
-      for (int d1 = 0; d1 < 4; ++d1) {
-        float p1[P];
-        double w[P];
-#pragma unroll
-        for (int q = 0; q < P; ++q) p1[q] = p0[q] * s_pwm[q][(G::PB + 1) * 4 + d1];
-        const uint32_t x = xlow | ((uint32_t)d0 << (2 * G::PB)) | ((uint32_t)d1 << (2 * (G::PB + 1)));
-        leaf(x, p1, w);
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-          acc[q][1][d1] += w[q];
-          s0[q] += w[q];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < P; ++q) {
-        acc[q][0][d0] += s0[q];
-        S[q] += s0[q];
-      }
-    }
   } else {
-    static_assert(G::HI == 4 || G::HI == 0 || G::HI == 2, "EM geometry");
-    // the two outer digits stay loops: unrolled 256 leaves deep the kernel needs > 256 VGPRs (one wave per SIMD)
-#pragma unroll 1
-    for (int d0 = 0; d0 < 4; ++d0) {
-      float p0[P];
-      double s0[P];
+    static_assert(G::HI >= 2, "EM geometry");
+    // HI digits per thread: the outer HI - 2 are walked by a run-time loop (unrolled 256 leaves deep the kernel
+    // needs > 256 VGPRs: one wave per SIMD), the inner two are unrolled: blocks of 16 leaves.
+    constexpr int OUT = G::HI - 2;
+    double so[P][OUT > 0 ? OUT : 1];  // running sums of the outer digits' cells
 #pragma unroll
-      for (int q = 0; q < P; ++q) {
-        p0[q] = pr[q] * s_pwm[q][(G::PB + 0) * 4 + d0];
-        s0[q] = 0.0;
-      }
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int jo = 0; jo < (OUT > 0 ? OUT : 1); ++jo) so[q][jo] = 0.0;
 #pragma unroll 1
-      for (int d1 = 0; d1 < 4; ++d1) {
-        float p1[P];
-        double s1[P];
+    for (int o = 0; o < (1 << (2 * OUT)); ++o) {
+      float po[P];  // product up to the last outer position, in position order like the reference's recursion
+      uint32_t xo = xlow;
+#pragma unroll
+      for (int q = 0; q < P; ++q) po[q] = pr[q];
+#pragma unroll
+      for (int jo = 0; jo < OUT; ++jo) {
+        const int dj = (o >> (2 * jo)) & 3;
+        xo |= (uint32_t)dj << (2 * (G::PB + jo));
+#pragma unroll
+        for (int q = 0; q < P; ++q) po[q] = po[q] * s_pwm[q][(G::PB + jo) * 4 + dj];
+      }
+      double s1[P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) s1[q] = 0.0;
+#pragma unroll
+      for (int d2 = 0; d2 < 4; ++d2) {
+        float p2[P];
+        double s2[P];
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-          p1[q] = p0[q] * s_pwm[q][(G::PB + 1) * 4 + d1];
-          s1[q] = 0.0;
+          p2[q] = po[q] * s_pwm[q][(G::PB + OUT) * 4 + d2];
+          s2[q] = 0.0;
         }
 #pragma unroll
-        for (int d2 = 0; d2 < 4; ++d2) {
-          float p2[P];
-          double s2[P];
+        for (int d3 = 0; d3 < 4; ++d3) {
+          float p3[P];
+          double w[P];
+#pragma unroll
+          for (int q = 0; q < P; ++q) p3[q] = p2[q] * s_pwm[q][(G::PB + OUT + 1) * 4 + d3];
+          const uint32_t x = xo | ((uint32_t)d2 << (2 * (G::PB + OUT))) | ((uint32_t)d3 << (2 * (G::PB + OUT + 1)));
+          leaf(x, p3, w);
 #pragma unroll
           for (int q = 0; q < P; ++q) {
-            p2[q] = p1[q] * s_pwm[q][(G::PB + 2) * 4 + d2];
-            s2[q] = 0.0;
-          }
-#pragma unroll
-          for (int d3 = 0; d3 < 4; ++d3) {
-            float p3[P];
-            double w[P];
-#pragma unroll
-            for (int q = 0; q < P; ++q) p3[q] = p2[q] * s_pwm[q][(G::PB + 3) * 4 + d3];
-            const uint32_t x = xlow | ((uint32_t)d0 << (2 * G::PB)) | ((uint32_t)d1 << (2 * (G::PB + 1))) |
-                               ((uint32_t)d2 << (2 * (G::PB + 2))) | ((uint32_t)d3 << (2 * (G::PB + 3)));
-            leaf(x, p3, w);
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-              acc[q][3][d3] += w[q];
-              s2[q] += w[q];
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < P; ++q) {
-            acc[q][2][d2] += s2[q];
-            s1[q] += s2[q];
+            acc[q][OUT + 1][d3] += w[q];
+            s2[q] += w[q];
           }
         }
-        // d0 and d1 are run-time loop counters: a select per cell keeps the accumulators in registers
-        // (indexing acc[..][d1] would send the whole array to scratch memory)
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-#pragma unroll
-          for (int a = 0; a < 4; ++a) acc[q][1][a] += (a == d1) ? s1[q] : 0.0;
-          s0[q] += s1[q];
+          acc[q][OUT][d2] += s2[q];
+          s1[q] += s2[q];
         }
       }
+      // the outer digits are run-time values: a select per cell keeps the accumulators in registers (indexing
+      // acc[..][dj] would send the whole array to scratch memory).  Digit jo changes every 4^jo blocks: its cells
+      // are updated then, from a running sum.
 #pragma unroll
       for (int q = 0; q < P; ++q) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[q][0][a] += (a == d0) ? s0[q] : 0.0;
-        S[q] += s0[q];
+        for (int jo = 0; jo < OUT; ++jo) {
+          so[q][jo] += s1[q];
+          if ((o & ((1 << (2 * jo)) - 1)) == (1 << (2 * jo)) - 1) {  // uniform; always true for jo = 0
+            const int dj = (o >> (2 * jo)) & 3;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[q][jo][a] += (a == dj) ? so[q][jo] : 0.0;
+            so[q][jo] = 0.0;
+          }
+        }
+        S[q] += s1[q];
       }
     }
   }
@@ -379,7 +356,8 @@ int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, flo
   // few PWMs: more, smaller workgroups so that every CU gets several waves
   if constexpr (W >= 8) {
     const int64_t wg4 = n_pwm * EmGeo<W, 4>::NB;
-    if (wg4 < (int64_t)ctx->num_cu * 8) return fast ? PENGK_EM_GEO(2, true, 1) : PENGK_EM_GEO(2, false, 1);
+    if (wg4 * 4 < (int64_t)ctx->num_cu * 4) return fast ? PENGK_EM_GEO(2, true, 1) : PENGK_EM_GEO(2, false, 1);
+    if (wg4 < (int64_t)ctx->num_cu * 8) return fast ? PENGK_EM_GEO(3, true, 1) : PENGK_EM_GEO(3, false, 1);
     // (P = 2, two PWMs per workgroup sharing every table read, was measured on the 1000-PWM batch: 4.51 ms against
     // 4.53 ms -- with the reads served from one cache line the kernel takes 3.2 ms, but what they cost is latency,
     // not bandwidth, and halving their number does not shorten it.)
