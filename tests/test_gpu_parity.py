@@ -594,3 +594,51 @@ def test_all_kernels_at_the_ends_of_the_length_range(ctx, W, both):
         want = acc / acc.sum(axis=1, keepdims=True)
         assert iters[0] == 1
         assert (np.abs(pw[0].astype(np.float64) - want) <= 1e-5 * np.abs(want)).all(), fast
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_count_fuzz_against_oracle(ctx, seed):
+    """Random small inputs over the whole parameter space of K1 (W, strand mode, emitter, item length, ragged and
+    too-short sequences, invalid bases, low-complexity stretches that trigger the non-overlap rule and the deferred
+    fix-up): counts, ltot and -- where the input is made of whole runs -- the fused background counters, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    W = int(rng.choice([4, 6, 8, 10, 12]))  # W = 14 (2 GiB oracle tables per case) has its own low-complexity test
+    both = bool(rng.integers(0, 2))
+    M = int(rng.choice([0, 64, 100, 256]))
+    impl = int(rng.choice([0, 1, 2])) if W in (8, 10, 12) else int(rng.choice([0, 1]))
+    n_seq = int(rng.integers(1, 400))
+    p_invalid = float(rng.choice([0.0, 0.0, 1e-3, 2e-2]))
+    seqs = []
+    for _ in range(n_seq):
+        kind = rng.integers(0, 10)
+        L = int(rng.integers(1, W)) if kind == 0 else int(rng.integers(W, 60)) if kind < 3 else int(rng.integers(60, 700)) \
+            if kind < 9 else int(rng.integers(2000, 6000))
+        s = rng.integers(1, 5, size=L).astype(np.uint8)
+        if rng.random() < 0.3 and L > 40:  # a low-complexity stretch: unit of length 1..12 repeated
+            unit = rng.integers(1, 5, size=int(rng.integers(1, 13))).astype(np.uint8)
+            a = int(rng.integers(0, L - 20))
+            b = min(L, a + int(rng.integers(20, 400)))
+            s[a:b] = np.tile(unit, (b - a) // len(unit) + 1)[:b - a]
+        if p_invalid:
+            s[rng.random(L) < p_invalid] = 0
+        seqs.append(s)
+    codes = np.concatenate(seqs)
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
+    want, ltot = po.count(codes, offs, W, both)
+    p = pk.Packed(codes, offs, W, M)
+    ctx.upload(p)
+    ctx.set_option("count_impl", impl)
+    try:
+        if p.all_whole:
+            counts, lt, bg = ctx.count_bg(both)
+            assert np.array_equal(bg.to_host().astype(np.int64), po.bg_counts(codes, offs, 2)), "bg"
+        else:
+            counts, lt = ctx.count(both)
+    finally:
+        ctx.set_option("count_impl", 0)
+    if both:
+        ctx.mirror(W, counts)
+    assert int(lt.to_host()[0]) == ltot
+    got = counts.to_host().astype(np.uint64)
+    assert np.array_equal(got, want), "W=%d both=%s M=%d impl=%d: %d bins differ" % (W, both, M, impl, int((got != want).sum()))
+    assert np.array_equal(p.bg_counts, po.bg_counts(codes, offs, 2))
