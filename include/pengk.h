@@ -74,7 +74,7 @@ int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
  * histograms (W = 8, 10, 12); "n_windows_hint" = total windows of the attached items (sizes the key buffer
  * tightly; set it after pengk_set_sequences); "key_cap_override" (test hook) entries per bucket region of the
  * partitioned count, 0 = automatic; "iupac_group_bytes" (test hook) scratch budget for one group of large
- * patterns in pengk_iupac_aggregate, 0 = 1 GiB; "em_fast" 1 (default) / 0, see pengk_em.  Info: "deferred_items" (of the last pengk_count;
+ * patterns in pengk_iupac_aggregate, 0 = 1 GiB; "em_fast" 1 (default) / 0 / 2, see pengk_em.  Info: "deferred_items" (of the last pengk_count;
  * synchronises), "num_cu". */
 int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value);
 int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value_out);
@@ -189,12 +189,18 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
 /* ---- K5: EM over the whole 4^W table (Peng::em_optimize_pwms + calculate_prob_odds,
  *      src/peng.cpp:48-197; row normalisation src/iupac_pattern.cpp:291-303) ----------------------
  * h_pwms: n_pwm x W x 4 floats, updated in place with the PWM the reference's loop ends on (before the
- * extra normalisation of the IUPACPattern(ori, pwm) constructor).  The float32 product over the PWM columns
- * is built in the reference's order; the per-k-mer weight c*s / (1 + s/(prod/bg)) is evaluated as
- * c*s*prod / (prod + s*bg) with one reciprocal (option "em_fast" = 1, the default; ~1 ulp per term) or with the
- * reference's three float32 divisions (option "em_fast" = 0, term-for-term the reference's bits).  The 4^W-term
- * sums are accumulated in fp64 in a fixed order in both modes (the reference adds serially in float32, error up
- * to 2.6e-4 relative), so results agree with the reference within BASELINE.json's 1e-5 relative either way.
+ * extra normalisation of the IUPACPattern(ori, pwm) constructor).  Three modes (option "em_fast"):
+ *   2  serial: the reference's float32 arithmetic including the ORDER in which it adds the 4^W weights of a PWM
+ *      cell (src/peng.cpp:121-127) -- PWMs, iteration counts and `change` are the reference's bit for bit.  One wave
+ *      pair per PWM walks each cell's terms in sequence: ~2 ms per iteration at W = 10 for up to a CU-count of PWMs
+ *      (11 ms for 1000), 16x that at W = 12.  What a caller needs when discrete decisions follow (motif merging compares
+ *      similarity scores that are exactly tied in real arithmetic for reverse-complement twins); the CLI's default.
+ *   0  the reference's float32 terms (three divisions per k-mer weight), summed in fp64 through a fixed tree.
+ *   1  (library default) the weight c*s / (1 + s/(prod/bg)) evaluated as c*s*prod / (prod + s*bg) with one
+ *      reciprocal (~1 ulp per term), fp64 tree sums: the throughput mode, 2.3e12 PWM-k-mer evaluations/s.
+ * Modes 0 and 1 agree with the reference within BASELINE.json's 1e-5 relative (the reference's own serial float32
+ * sums are off by up to 2.6e-4 relative from the exact ones); the float32 product over the PWM columns is built in
+ * the reference's order in all modes.
  * h_iters / h_change (optional): iterations run and last `change` per PWM. */
 int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturation, float threshold,
              int max_iterations, const uint32_t* d_counts, const float* d_bg, int* h_iters, float* h_change);

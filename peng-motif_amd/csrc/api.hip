@@ -118,7 +118,7 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     return PENGK_OK;
   }
   if (strcmp(name, "em_fast") == 0) {
-    if (value < 0 || value > 1) return fail(PENGK_ERR_ARG, "em_fast must be 0 or 1");
+    if (value < 0 || value > 2) return fail(PENGK_ERR_ARG, "em_fast must be 0 (reference terms), 1 (fast) or 2 (serial, bit-exact)");
     ctx->em_fast = (int)value;
     return PENGK_OK;
   }

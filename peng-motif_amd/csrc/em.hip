@@ -15,6 +15,8 @@
 // reference adds them serially in float32 (error up to 2.6e-4 relative at W=10);
 // here they are accumulated in fp64 through a fixed tree (thread -> wave -> block -> grid), so the
 // result is deterministic and within 1 ulp(float) of the exact sum.
+#include <algorithm>
+
 #include "pengk_internal.h"
 
 namespace pengk {
@@ -258,6 +260,120 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// em_fast = 2, "serial": the reference's float32 arithmetic INCLUDING its summation order, bit for bit.
+// The reference adds the 4^W weights into each PWM cell one after the other in float32 (src/peng.cpp:121-127);
+// the motifs' merge and redundancy decisions downstream compare similarity scores that are exactly tied in real
+// arithmetic for reverse-complement twins, so the last bits of those sums decide what the program prints.
+// A cell's sum is inherently sequential, but cells and PWMs are independent and the weights are not:
+//   em_weights_kernel  all weights w(x) of a PWM in parallel (reference float operations), to a scratch table;
+//   em_fold_kernel     two waves per PWM, one lane per cell (p, a): the lane walks ITS terms -- the x whose digit p
+//                      is a, ascending -- with the next group of loads in flight while it adds the current one.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
+                                                         const uint32_t* __restrict__ counts, const float* __restrict__ bg,
+                                                         float saturation, float* __restrict__ wbuf) {
+  const int pw = blockIdx.y;
+  if (state[2 * pw + 1] == 0) return;
+  __shared__ float s_pwm[W * 4];
+  if (threadIdx.x < W * 4) s_pwm[threadIdx.x] = pwms[(size_t)pw * W * 4 + threadIdx.x];
+  __syncthreads();
+  const uint32_t np = 1u << (2 * W);
+  float* out = wbuf + (size_t)pw * np;
+  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
+    float pr = 1.0f;  // src/peng.cpp:180-197: ((1*pwm[0][x0])*pwm[1][x1])...
+#pragma unroll
+    for (int p = 0; p < W; ++p) pr = pr * s_pwm[p * 4 + ((x >> (2 * p)) & 3u)];
+    const float odds = pr / bg[x];
+    out[x] = ((float)counts[x] * saturation) / (1 + saturation / odds);  // :124-125
+  }
+}
+
+// Two waves per PWM.  Wave 0: the cells of positions p >= 1 -- their terms come in aligned groups of four consecutive x,
+// one 16-byte load per group (a dword load per term costs one cache-line request per lane and term: 40 requests per
+// instruction made the first version of this kernel 3.8 ms per iteration at W = 10).  Wave 1: the four cells of position
+// 0, whose terms are every fourth x: lanes 0..3 read the same 16 bytes and take one component each.
+template <int W>
+__global__ __launch_bounds__(128) void em_fold_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
+                                                      double* __restrict__ partials) {
+  const int pw = blockIdx.x;
+  if (state[2 * pw + 1] == 0) return;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t np = 1u << (2 * W);
+  const uint32_t n_terms = np / 4u;  // per cell
+  const float* w = wbuf + (size_t)pw * np;
+  constexpr uint32_t DEPTH = (W >= 6) ? 4u : 1u;  // chunks of 16 terms per register buffer
+  static_assert(((1u << (2 * W - 2)) / 16u) % (2u * DEPTH) == 0u, "chunk count");
+  const uint32_t group = 16u * DEPTH;
+  float acc = 0.0f;
+  if (wave == 0) {
+    const uint32_t cell = lane + 4u;
+    if (cell >= (uint32_t)(W * 4)) return;
+    const uint32_t p = cell >> 2, a = cell & 3u;
+    const uint32_t run = 1u << (2 * p);  // the cell's terms come in runs of 4^p consecutive x, one run per 4^(p+1)
+    // term t is x(t) = ((t >> 2p) << (2p+2)) | (a << 2p) | (t & (run-1)); a chunk of 16 consecutive terms (t0 a
+    // multiple of 16) is four aligned quads: consecutive for runs >= 16, one quad per run for runs of 4 (p = 1)
+    const uint32_t quad_step = run >= 16u ? 4u : 16u;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto load_group = [&](uint32_t t0, f4 (&v)[DEPTH][4]) {
+#pragma unroll
+      for (uint32_t c = 0; c < DEPTH; ++c) {
+        const uint32_t t = t0 + 16u * c;
+        const uint32_t x0 = ((t >> (2 * p)) << (2 * p + 2)) | (a << (2 * p)) | (t & (run - 1u));
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) v[c][k] = *reinterpret_cast<const f4*>(w + x0 + k * quad_step);
+      }
+    };
+    auto add_group = [&](const f4 (&v)[DEPTH][4]) {  // strictly in order: this IS the reference's rounding sequence
+#pragma unroll
+      for (uint32_t c = 0; c < DEPTH; ++c)
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+          acc += v[c][k].x;
+          acc += v[c][k].y;
+          acc += v[c][k].z;
+          acc += v[c][k].w;
+        }
+    };
+    f4 va[DEPTH][4], vb[DEPTH][4];
+    load_group(0, va);
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < n_terms; t0 += 2u * group) {
+      load_group(t0 + group, vb);
+      add_group(va);
+      if (t0 + 2u * group < n_terms) load_group(t0 + 2u * group, va);
+      add_group(vb);
+    }
+    partials[(size_t)pw * (W * 4) + cell] = (double)acc;  // layout of EmGeo<W, 16>: one "block" per PWM
+  } else {
+    if (lane >= 4u) return;
+    const uint32_t a = lane;  // position 0: term t is x = 4t + a
+    auto load_group = [&](uint32_t t0, float (&v)[DEPTH][16]) {
+#pragma unroll
+      for (uint32_t c = 0; c < DEPTH; ++c)
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) v[c][k] = w[4u * (t0 + 16u * c + k) + a];
+    };
+    auto add_group = [&](const float (&v)[DEPTH][16]) {
+#pragma unroll
+      for (uint32_t c = 0; c < DEPTH; ++c)
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) acc += v[c][k];
+    };
+    float va[DEPTH][16], vb[DEPTH][16];
+    load_group(0, va);
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < n_terms; t0 += 2u * group) {
+      load_group(t0 + group, vb);
+      add_group(va);
+      if (t0 + 2u * group < n_terms) load_group(t0 + 2u * group, va);
+      add_group(vb);
+    }
+    partials[(size_t)pw * (W * 4) + a] = (double)acc;
+  }
+}
+
 // One block per PWM: sum the per-block partials in block order, then the reference's float32
 // epilogue: normalise rows (:129), change = sum |new - old| (:132-137), swap (:140-143).
 template <int W, int HIMAX>
@@ -349,9 +465,45 @@ int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, f
 }
 
 template <int W>
+int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
+                  const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
+  using G = EmGeo<W, 16>;  // HI = W - 4, one partial block per PWM
+  static_assert(G::NB == 1, "serial mode writes one row of cells per PWM");
+  static_assert(W >= 4, "a cell has at least 16 terms");
+  hipLaunchKernelGGL(em_init_kernel, dim3((unsigned)((n_pwm + 255) / 256)), dim3(256), 0, ctx->stream, (int)n_pwm, W, threshold,
+                     max_it, d_state, d_change);
+  PENGK_HIP(hipGetLastError());
+  const size_t np = (size_t)1 << (2 * W);
+  const size_t budget = (size_t)1 << 30;  // weight tables of one batch of PWMs
+  int64_t batch = (int64_t)(budget / (np * sizeof(float)));
+  if (batch < 1) batch = 1;
+  if (batch > n_pwm) batch = n_pwm;
+  if (batch > 65535) batch = 65535;  // gridDim.y
+  int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, (size_t)batch * np * sizeof(float));
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, (size_t)batch * G::CELLS * sizeof(double));
+  if (rc) return rc;
+  const unsigned wb = (unsigned)std::min<size_t>((np + 255) / 256, 1024);
+  for (int64_t first = 0; first < n_pwm; first += batch) {
+    const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
+    for (int it = 0; it < max_it; ++it) {
+      hipLaunchKernelGGL((em_weights_kernel<W>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
+                         d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables);
+      hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)nb), dim3(128), 0, ctx->stream, d_state + 2 * first, ctx->d_em_tables,
+                         ctx->d_em_partials);
+      hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
+                         d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it);
+    }
+    PENGK_HIP(hipGetLastError());
+  }
+  return PENGK_OK;
+}
+
+template <int W>
 int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
              const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
 #define PENGK_EM_GEO(H, F, PP) launch_geo<W, H, F, PP>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change)
+  if (ctx->em_fast == 2) return launch_serial<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
   const bool fast = ctx->em_fast != 0;
   // few PWMs: more, smaller workgroups so that every CU gets several waves
   if constexpr (W >= 8) {

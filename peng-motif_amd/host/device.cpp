@@ -47,9 +47,13 @@ pengk_ctx* context() {
   static bool options_set = false;
   if (!options_set) {
     options_set = true;
-    // PENGK_EM_FAST=0: the reference's three float divisions per k-mer weight in the EM instead of one reciprocal
-    // (the default; results agree within 1e-5 relative, see include/pengk.h)
-    if (const char* e = std::getenv("PENGK_EM_FAST")) check(pengk_set_option(g_ctx, "em_fast", std::atoi(e) ? 1 : 0), "pengk_set_option");
+    // The CLI runs the EM in the library's serial mode (em_fast = 2): the reference's float32 arithmetic including its
+    // summation order, so that the merge / redundancy decisions downstream -- exact ties in real arithmetic for
+    // reverse-complement twins -- fall as the reference's do.  PENGK_EM_FAST=1 (one reciprocal per weight, fp64 tree
+    // sums, ~10x faster for large PWM sets) or 0 (reference terms, fp64 tree sums) select the throughput modes.
+    int mode = 2;
+    if (const char* e = std::getenv("PENGK_EM_FAST")) mode = std::atoi(e);
+    check(pengk_set_option(g_ctx, "em_fast", mode), "pengk_set_option");
   }
   return g_ctx;
 }

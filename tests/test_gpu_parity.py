@@ -642,3 +642,29 @@ def test_count_fuzz_against_oracle(ctx, seed):
     got = counts.to_host().astype(np.uint64)
     assert np.array_equal(got, want), "W=%d both=%s M=%d impl=%d: %d bins differ" % (W, both, M, impl, int((got != want).sum()))
     assert np.array_equal(p.bg_counts, po.bg_counts(codes, offs, 2))
+
+
+@pytest.mark.parametrize("name", ["mafk100_w8_both", "mafk100_w8_plus", "torture_w6_plus", "mafk_w10_both", "mafk_w10_plus"])
+def test_em_serial_mode_is_bit_exact(ctx, golden_dir, name):
+    """em_fast = 2 reproduces the reference's float32 arithmetic including the ORDER in which it adds the 4^W weights
+    of a PWM cell: PWMs, iteration counts and the last `change` equal the oracle's serial mode bit for bit, and after the
+    constructor's extra normalisation (src/iupac_pattern.cpp:61) the PWMs the compiled reference produced."""
+    r = cpu_pipeline(golden_dir, name)
+    g = r["g"]
+    W, K = r["W"], r["K"]
+    if len(g["pwm_ids"]) == 0:
+        pytest.skip("no PWMs in this case")
+    d = gpu_tables(ctx, r)
+    bg_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K])
+    ctx.set_option("em_fast", 2)
+    try:
+        pw, iters, change = ctx.em(W, g["pwm_pre"], d["counts"], bg_k, 1e4, 0.08, 10)
+    finally:
+        ctx.set_option("em_fast", 1)
+    for i in range(len(g["pwm_ids"])):
+        p0, it0, ch0 = po.em(W, r["counts"], r["bgp"][K], g["pwm_pre"][i], 1e4, 0.08, 10, mode=0, final_norm=False)
+        assert iters[i] == it0 == int(g["em_iters"][i])
+        assert bits_equal(pw[i], p0), i
+        assert np.float32(change[i]).view(np.uint32) == np.float32(ch0).view(np.uint32)
+        fin = pw[i] / pw[i].sum(axis=1, keepdims=True, dtype=np.float32)
+        assert bits_equal(fin.astype(np.float32), g["pwm_post"][i].astype(np.float32)), i
