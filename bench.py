@@ -200,6 +200,21 @@ def main():
                 best = ms if best is None else min(best, ms)
             em_stress = (n_st, best)
 
+        # ---- the bit-exact serial EM mode (what the CLI runs) on the step's own PWM batch, for the record ----------------
+        em_serial_ms = None
+        if n_my and args.em_fast != 2:
+            ctx.set_option("em_fast", 2)
+            t_a, t_b = ctx.timer(), ctx.timer()
+            for rep in range(2):
+                pwms.copy_(pw_init)
+                ctx.record(t_a)
+                pk._check(lib.pengk_em_device(ctx.h, W, n_my, pwms.data_ptr(), 1e4, 0.0, args.em_iters, counts.data_ptr(),
+                                              bgprob[K].data_ptr(), em_state.data_ptr(), em_change.data_ptr()))
+                ctx.record(t_b)
+                ms = ctx.elapsed_ms(t_a, t_b)
+                em_serial_ms = ms if em_serial_ms is None else min(em_serial_ms, ms)
+            ctx.set_option("em_fast", args.em_fast)
+
         # ---- K4 probe (not part of the step): the mutants of one hill-climb round, 1 .. 6 degenerate letters each ----
         k4 = None
         if args.k4_patterns > 0:
@@ -259,6 +274,7 @@ def main():
                 "em_stress_ms": round(em_stress[1], 4) if em_stress else None,
                 "em_stress_evals_per_s_per_gpu": round(em_stress[0] * args.em_iters * NP / (em_stress[1] * 1e-3), 1)
                 if em_stress and em_stress[1] else None,
+                "em_serial_mode_ms": round(em_serial_ms, 4) if em_serial_ms else None,
                 # K4 (host call incl. id upload, result download and the libm epilogue): patterns and underlying k-mers
                 "k4_patterns": k4[0] if k4 else None, "k4_ms": round(k4[2] * 1e3, 4) if k4 else None,
                 "k4_kmers_visited_per_s": round(k4[1] / k4[2], 1) if k4 else None,
