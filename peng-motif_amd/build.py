@@ -25,7 +25,7 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-EXTRA = os.environ.get("PENGK_EXTRA_FLAGS", "").split()  # experiments, e.g. -DPENGK_RING_CAP=64
+EXTRA = os.environ.get("PENGK_EXTRA_FLAGS", "").split()  # experiments, e.g. -DPENGK_ABLATE=8
 
 
 def needs_build():

@@ -19,12 +19,10 @@
 
 #include "pengk_internal.h"
 
-#ifndef PENGK_RING_CAP
-#define PENGK_RING_CAP 128
-#endif
 #ifndef PENGK_ABLATE
-#define PENGK_ABLATE 0  // timing experiments (compile time): 1 = never flush, 2 = no append at all, 4 = no fused K1b,
-                        // 8 = conflict-free bucket per lane (wrong results)
+#define PENGK_ABLATE 0  // timing experiments (compile time, wrong results): 1 = never flush, 2 = no append at all,
+                        // 4 = no fused K1b, 8 = conflict-free bucket per lane, 16 = no LDS read in the flush,
+                        // 32 = no key store (tools/ablate.sh)
 #endif
 
 namespace pengk {
@@ -279,8 +277,8 @@ __global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 // K1 variant 2 ("partition"): LDS-privatised histograms for 4^W bins that do not fit in LDS.
 //
-//   pass A  count_scatter_kernel: the same scan, but a counted window's id is split into
-//           bucket = id & (NB-1) and a 15-bit payload = id >> NBITS.  Every wave owns NB small
+//   pass A  count_scatter_kernel: the same scan, but a counted window's id is split into a bucket
+//           (NBITS bits from the middle of the id, see KeySplit) and a 15-bit payload.  Every wave owns NB small
 //           rings in LDS (128 x u16 each); whenever a ring completes a group of 64 payloads the
 //           wave writes them as ONE 128-byte line into ITS OWN slice of the bucket's region of a
 //           key buffer in HBM.  The slices are static (region[wave][bucket][slice_cap]): no
@@ -289,12 +287,12 @@ __global__ __launch_bounds__(256) void count_kernel(const uint32_t* __restrict__
 //   pass B  count_hist_kernel: a workgroup owns part of one bucket, keeps the bucket's 2^15 bins in
 //           128 KiB of LDS, streams the slices (16 B per lane) and counts with LDS atomics; the
 //           block histogram is added to a bucket-major table with coalesced atomics.
-//   pass C  count_gather_kernel: table[(payload << NBITS) | bucket] += bucket-major table.
+//   pass C  count_gather_kernel: table[join(bucket, payload)] += bucket-major table.
 //
 // Skewed inputs cannot break it: a slice that runs full makes further groups of that (wave, bucket)
 // fall back to direct atomics on the final table (graceful degradation to variant 1).
 // ---------------------------------------------------------------------------------------------
-constexpr int RING_CAP = PENGK_RING_CAP;  // u16 entries per (wave, bucket) ring
+constexpr int RING_CAP = 128;           // u16 entries per (wave, bucket) ring: a group of 64 plus 64 in flight
 constexpr int GROUP = RING_CAP / 2;        // entries written per flush (one 128-byte line at RING_CAP = 128)
 constexpr uint32_t KEY_INVALID = 0xFFFFu;
 constexpr int PAYLOAD_BITS = 15;
@@ -369,7 +367,7 @@ __device__ __forceinline__ ScatterShared<NBITS>& scatter_lds() {
 // s goes to slice entries [s - 63, s], an address formed from wave-uniform scalars (SALU) plus lane * 2.  Ring
 // payloads written by other lanes are read with a wavefront-scope atomic load.  (Earlier versions kept a write
 // cursor per bucket in LDS words -- the compiler legally re-used stale copies -- and then in the registers of
-// lane b: three v_readlane, a 64-bit add and two selects per flush, all on the VALU this kernel is bound by.)
+// lane b: three v_readlane, a 64-bit add and two selects per flush.)
 template <class KS, int NBITS>
 struct ScatterEmit {
   static constexpr int NB = 1 << NBITS;
@@ -1005,7 +1003,7 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
   // grid of pass A: LDS (33 KiB per block at NB = 32) admits 4 blocks per CU
   const uint32_t blocks_needed = (n_items + 255) / 256;
-  uint32_t per_cu = RING_CAP >= 128 ? 4u : 8u;
+  uint32_t per_cu = 4u;
   if (const char* e = getenv("PENGK_SCATTER_BLOCKS_PER_CU")) per_cu = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : per_cu;  // experiments
   const uint32_t max_blocks = (uint32_t)ctx->num_cu * per_cu;
   const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
