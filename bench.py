@@ -264,7 +264,10 @@ def main():
             "config": {"workload": "synthetic %dx%d bp per GPU, W=%d, %s strands, bg-order 2 (BASELINE configs[2]); step = count + all-reduce + sweep + EM(%d PWMs x %d it)"
                        % (nseq, L, W, "both" if both else "plus", P_total, args.em_iters),
                        "n_seq_per_gpu": nseq, "seq_len": L, "W": W, "strand": args.strand, "ltot_global": ltot,
-                       "parallelism": "sequence shards x%d, one all-reduce of the 4^W counts" % world},
+                       "parallelism": "sequence shards x%d, one all-reduce of the 4^W counts" % world,
+                       "em_mode": {0: "reference terms, fp64 tree sums (1e-5 rel.)", 1: "one reciprocal per weight, fp64 tree sums (1e-5 rel., BASELINE.json's bar)",
+                                   2: "serial float32, bit-exact"}[args.em_fast]
+                                  + "; the bit-exact serial mode the CLI uses is timed separately: components.em_serial_mode_ms"},
             "components": {
                 "count_gbp_per_s_per_gpu": round(nseq * L / (count_ms * 1e-3) / 1e9, 3) if count_ms else None,
                 "zscores_per_s": round(NP / (sweep_ms * 1e-3), 1) if sweep_ms else None,
