@@ -1,6 +1,6 @@
 """Differential sweep (GPU box, needs oracle/_ref/peng_motif_ref): random FASTA inputs and random flag combinations through
 the compiled reference and through this repository's peng_motif; MEME, JSON and stdout must be identical byte for byte.
-usage: python tests/tools/cli_differential.py FIRST_SEED N_CASES"""
+usage: [SCALE=100] python tests/tools/cli_differential.py FIRST_SEED N_CASES   (SCALE multiplies the number of sequences)"""
 import os
 import subprocess
 import sys
@@ -16,7 +16,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "peng_motif_ref")
 def make_case(seed, tmp):
     rng = np.random.default_rng(9000 + seed)
     W = int(rng.choice([4, 6, 8, 8, 10, 10, 12]))
-    n, L = int(rng.integers(100, 1200)), int(rng.integers(max(W + 2, 30), 260))
+    n, L = int(rng.integers(100, 1200)) * int(os.environ.get("SCALE", "1")), int(rng.integers(max(W + 2, 30), 260))
     motifs = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(6, 14)))) for _ in range(int(rng.integers(1, 5)))]
     p_n = float(rng.choice([0.0, 0.02, 0.2]))
 
