@@ -408,7 +408,7 @@ struct ScatterEmit {
   __device__ __forceinline__ void store_line(uint32_t off, uint32_t v) const {
     // explicit global address space (a flat store would stall LDS waits); scalar base + lane * 2
     global_u16* dst = (global_u16*)(keys + ((size_t)wave_global * NB * slice_cap + (size_t)off));
-    if (!(PENGK_ABLATE & 32)) dst[lane] = (uint16_t)v;
+    if (!(PENGK_ABLATE & 32)) __builtin_nontemporal_store((uint16_t)v, &dst[lane]);  // written once, read once by pass B
   }
   template <bool PARTIAL>
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
@@ -645,7 +645,11 @@ __global__ __launch_bounds__(1024) void count_hist_kernel(const uint16_t* __rest
     for (; i + 448 < n8; i += 512) {  // eight 16-byte loads in flight per lane before their 64 LDS adds
       uint4 v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = src[i + 64 * q];
+      for (int q = 0; q < 8; ++q) {  // streamed once: non-temporal
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&src[i + 64 * q]));
+        v[q] = make_uint4(t.x, t.y, t.z, t.w);
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) count8(v[q]);
     }
