@@ -534,7 +534,7 @@ struct Scatter32Emit {
     if ((lane & 31u) >= nvalid) v = KEY32_INVALID;
     if (g0 + (uint32_t)GROUP32 <= slice_cap) {  // wave-uniform
       global_u32* dst = (global_u32*)(keys + ((size_t)wave_global * 32u * slice_cap + (size_t)(b * slice_cap + g0)));
-      if (lane < 32u) dst[lane] = v;
+      if (lane < 32u) __builtin_nontemporal_store(v, &dst[lane]);
     } else if (lane < 32u && v != KEY32_INVALID) {  // slice full: count directly
       __hip_atomic_fetch_add(&hist[Split12L1::join(b, v)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
     const uint32_t n = fill1[(size_t)s * 32u + b1];  // multiple of GROUP32
     const uint32_t* src = keys1 + ((size_t)s * 32u + b1) * cap1;
     for (uint32_t i = 0; i < n; i += 64) {  // wave-uniform trip count
-      const uint32_t k = (i + lane < n) ? src[i + lane] : KEY32_INVALID;
+      const uint32_t k = (i + lane < n) ? __builtin_nontemporal_load(&src[i + lane]) : KEY32_INVALID;
       e(k, k != KEY32_INVALID);
     }
   }
