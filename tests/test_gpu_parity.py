@@ -668,3 +668,27 @@ def test_em_serial_mode_is_bit_exact(ctx, golden_dir, name):
         assert np.float32(change[i]).view(np.uint32) == np.float32(ch0).view(np.uint32)
         fin = pw[i] / pw[i].sum(axis=1, keepdims=True, dtype=np.float32)
         assert bits_equal(fin.astype(np.float32), g["pwm_post"][i].astype(np.float32)), i
+
+
+def test_em_serial_mode_many_pwms_in_batches(ctx, golden_dir):
+    """300 PWMs at W = 10 exceed one batch of the serial mode's weight tables (1 GiB = 256 PWMs): the second batch must be
+    as bit-exact as the first (sampled PWMs against the oracle's serial mode, 2 iterations)."""
+    r = cpu_pipeline(golden_dir, "mafk_w10_plus")
+    W, K = r["W"], r["K"]
+    d = gpu_tables(ctx, r)
+    bg_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K])
+    order = np.lexsort((np.arange(4 ** W), -r["counts"].astype(np.int64)))[:300]
+    pwms = np.full((len(order), W, 4), 0.1, np.float32)
+    for i, x in enumerate(order):
+        for p_ in range(W):
+            pwms[i, p_, (int(x) >> (2 * p_)) & 3] = 0.7
+    ctx.set_option("em_fast", 2)
+    try:
+        pw, iters, change = ctx.em(W, pwms, d["counts"], bg_k, 1e4, 0.0, 2)
+    finally:
+        ctx.set_option("em_fast", 1)
+    assert (iters == 2).all()
+    for i in (0, 255, 256, 299):
+        p0, it0, ch0 = po.em(W, r["counts"], r["bgp"][K], pwms[i], 1e4, 0.0, 2, mode=0, final_norm=False)
+        assert bits_equal(pw[i], p0), i
+        assert np.float32(change[i]).view(np.uint32) == np.float32(ch0).view(np.uint32)
