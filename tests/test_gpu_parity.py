@@ -688,7 +688,7 @@ def test_em_serial_mode_many_pwms_in_batches(ctx, golden_dir):
     finally:
         ctx.set_option("em_fast", 1)
     assert (iters == 2).all()
-    for i in (0, 255, 256, 299):
+    for i in (0, 1, 2, 3, 255, 256, 297, 298, 299):
         p0, it0, ch0 = po.em(W, r["counts"], r["bgp"][K], pwms[i], 1e4, 0.0, 2, mode=0, final_norm=False)
         assert bits_equal(pw[i], p0), i
         assert np.float32(change[i]).view(np.uint32) == np.float32(ch0).view(np.uint32)
