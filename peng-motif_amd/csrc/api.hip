@@ -34,9 +34,22 @@ int ensure_scratch(pengk_ctx* ctx, void** slot, size_t* have, size_t need) {
   return PENGK_OK;
 }
 
+// Every entry point that launches, allocates or copies runs on the context's device, whatever device the calling
+// thread had current (the CLI creates the context on a helper thread and uses it from the main thread).
+int enter(pengk_ctx* ctx) {
+  PENGK_HIP(hipSetDevice(ctx->device));
+  return PENGK_OK;
+}
+
 }  // namespace pengk
 
 using namespace pengk;
+
+#define PENGK_ENTER(ctx)               \
+  do {                                 \
+    int rc_enter_ = ::pengk::enter(ctx); \
+    if (rc_enter_) return rc_enter_;   \
+  } while (0)
 
 extern "C" {
 
@@ -79,6 +92,12 @@ int pengk_create(int device, pengk_ctx** out) {
     return hip_fail(e, "hipStreamCreate");
   }
   c->own_stream = true;
+  int rc = count_init_device();  // per-device kernel attributes (128 KiB dynamic LDS of pass B)
+  if (rc) {
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return rc;
+  }
   *out = c;
   return PENGK_OK;
 }
@@ -102,6 +121,7 @@ int pengk_destroy(pengk_ctx* ctx) {
 
 int pengk_synchronize(pengk_ctx* ctx) {
   if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  PENGK_ENTER(ctx);
   PENGK_HIP(hipStreamSynchronize(ctx->stream));
   return PENGK_OK;
 }
@@ -126,6 +146,11 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     ctx->iupac_group_bytes = (uint64_t)value;
     return PENGK_OK;
   }
+  if (strcmp(name, "scatter_blocks_per_cu") == 0) {
+    if (value < 0 || value > 8) return fail(PENGK_ERR_ARG, "scatter_blocks_per_cu must be 0 (default) .. 8");
+    ctx->scatter_blocks_per_cu = (int)value;
+    return PENGK_OK;
+  }
   if (strcmp(name, "n_windows_hint") == 0) {
     ctx->n_windows_hint = (uint64_t)value;
     return PENGK_OK;
@@ -135,6 +160,7 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
 
 int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value) {
   if (!ctx || !name || !value) return fail(PENGK_ERR_ARG, "pengk_get_info: NULL argument");
+  PENGK_ENTER(ctx);
   if (strcmp(name, "deferred_items") == 0) {  // scan items the last pengk_count handed to the exact fallback
     uint32_t n = 0;
     if (ctx->d_defer) {
@@ -155,6 +181,7 @@ void* pengk_stream(pengk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 
 int pengk_set_stream(pengk_ctx* ctx, void* s) {
   if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  PENGK_ENTER(ctx);
   PENGK_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->own_stream && ctx->stream) PENGK_HIP(hipStreamDestroy(ctx->stream));
   ctx->stream = (hipStream_t)s;
@@ -172,6 +199,7 @@ int pengk_malloc(pengk_ctx* ctx, size_t bytes, void** d_out) {
 
 int pengk_free(pengk_ctx* ctx, void* d_ptr) {
   if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  PENGK_ENTER(ctx);
   if (d_ptr) {
     PENGK_HIP(hipStreamSynchronize(ctx->stream));
     PENGK_HIP(hipFree(d_ptr));
@@ -189,6 +217,7 @@ int pengk_host_alloc(pengk_ctx* ctx, size_t bytes, void** h_out) {
 
 int pengk_host_free(pengk_ctx* ctx, void* h_ptr) {
   if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  PENGK_ENTER(ctx);
   if (h_ptr) {
     PENGK_HIP(hipStreamSynchronize(ctx->stream));
     PENGK_HIP(hipHostFree(h_ptr));
@@ -198,6 +227,7 @@ int pengk_host_free(pengk_ctx* ctx, void* h_ptr) {
 
 int pengk_memcpy_h2d(pengk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   if (!ctx || (bytes && (!d_dst || !h_src))) return fail(PENGK_ERR_ARG, "pengk_memcpy_h2d: NULL argument");
+  PENGK_ENTER(ctx);
   PENGK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   PENGK_HIP(hipStreamSynchronize(ctx->stream));
   return PENGK_OK;
@@ -205,6 +235,7 @@ int pengk_memcpy_h2d(pengk_ctx* ctx, void* d_dst, const void* h_src, size_t byte
 
 int pengk_memcpy_d2h(pengk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   if (!ctx || (bytes && (!h_dst || !d_src))) return fail(PENGK_ERR_ARG, "pengk_memcpy_d2h: NULL argument");
+  PENGK_ENTER(ctx);
   PENGK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   PENGK_HIP(hipStreamSynchronize(ctx->stream));
   return PENGK_OK;
@@ -212,12 +243,14 @@ int pengk_memcpy_d2h(pengk_ctx* ctx, void* h_dst, const void* d_src, size_t byte
 
 int pengk_memset(pengk_ctx* ctx, void* d_dst, int byte, size_t bytes) {
   if (!ctx || (bytes && !d_dst)) return fail(PENGK_ERR_ARG, "pengk_memset: NULL argument");
+  PENGK_ENTER(ctx);
   PENGK_HIP(hipMemsetAsync(d_dst, byte, bytes, ctx->stream));
   return PENGK_OK;
 }
 
 int pengk_timer_create(pengk_ctx* ctx, void** out) {
   if (!ctx || !out) return fail(PENGK_ERR_ARG, "pengk_timer_create: NULL argument");
+  PENGK_ENTER(ctx);
   hipEvent_t ev;
   PENGK_HIP(hipEventCreate(&ev));
   *out = (void*)ev;
@@ -225,11 +258,13 @@ int pengk_timer_create(pengk_ctx* ctx, void** out) {
 }
 int pengk_timer_record(pengk_ctx* ctx, void* t) {
   if (!ctx || !t) return fail(PENGK_ERR_ARG, "pengk_timer_record: NULL argument");
+  PENGK_ENTER(ctx);
   PENGK_HIP(hipEventRecord((hipEvent_t)t, ctx->stream));
   return PENGK_OK;
 }
 int pengk_timer_elapsed_ms(pengk_ctx* ctx, void* a, void* b, float* ms) {
   if (!ctx || !a || !b || !ms) return fail(PENGK_ERR_ARG, "pengk_timer_elapsed_ms: NULL argument");
+  PENGK_ENTER(ctx);
   PENGK_HIP(hipEventSynchronize((hipEvent_t)b));
   PENGK_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
   return PENGK_OK;
@@ -277,6 +312,7 @@ int pengk_synth_sizes(uint64_t n_seq, uint32_t L, int W, int item_windows, uint6
 int pengk_synth_sequences(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t n_seq, uint32_t L, int W,
                           int item_windows, uint64_t* d_words, uint64_t* d_items) {
   if (!ctx || !d_words || !d_items) return fail(PENGK_ERR_ARG, "pengk_synth_sequences: NULL argument");
+  PENGK_ENTER(ctx);
   if (item_windows == 0) item_windows = PENGK_DEFAULT_ITEM_WINDOWS;
   uint64_t nw = 0, ni = 0;
   int rc = pengk_synth_sizes(n_seq, L, W, item_windows, &nw, &ni);
@@ -294,6 +330,7 @@ int pengk_synth_sequences(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t
 int pengk_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) {
   if (!ctx || !d_counts || !d_ltot) return fail(PENGK_ERR_ARG, "pengk_count: NULL argument");
   if (!ctx->d_words) return fail(PENGK_ERR_ARG, "pengk_count: no sequences attached");
+  PENGK_ENTER(ctx);
   if (ctx->max_bin_bound >= (1ull << 32))
     return fail(PENGK_ERR_RANGE, "a count bin could reach %llu >= 2^32 on this shard; split the input",
                 (unsigned long long)ctx->max_bin_bound);
@@ -303,6 +340,7 @@ int pengk_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot) 
 int pengk_count_bg(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg) {
   if (!ctx || !d_counts || !d_ltot || !d_bg) return fail(PENGK_ERR_ARG, "pengk_count_bg: NULL argument");
   if (!ctx->d_words) return fail(PENGK_ERR_ARG, "pengk_count_bg: no sequences attached");
+  PENGK_ENTER(ctx);
   if (!ctx->all_whole)
     return fail(PENGK_ERR_UNSUPPORTED, "pengk_count_bg: input has invalid bases or sequences shorter than W; use pengk_packed.bg_counts");
   if (ctx->max_bin_bound >= (1ull << 32))
@@ -313,6 +351,7 @@ int pengk_count_bg(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_lto
 
 int pengk_mirror_counts(pengk_ctx* ctx, int W, uint32_t* d_counts) {
   if (!ctx || !d_counts) return fail(PENGK_ERR_ARG, "pengk_mirror_counts: NULL argument");
+  PENGK_ENTER(ctx);
   if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
   return launch_mirror(ctx, W, d_counts);
 }
@@ -320,6 +359,7 @@ int pengk_mirror_counts(pengk_ctx* ctx, int W, uint32_t* d_counts) {
 int pengk_bg_count(pengk_ctx* ctx, uint64_t* d_bg) {
   if (!ctx || !d_bg) return fail(PENGK_ERR_ARG, "pengk_bg_count: NULL argument");
   if (!ctx->d_words) return fail(PENGK_ERR_ARG, "pengk_bg_count: no sequences attached");
+  PENGK_ENTER(ctx);
   if (!ctx->all_whole)
     return fail(PENGK_ERR_UNSUPPORTED, "pengk_bg_count: input has invalid bases or sequences shorter than W; use pengk_packed.bg_counts");
   return launch_bg_count(ctx, d_bg);
@@ -327,6 +367,7 @@ int pengk_bg_count(pengk_ctx* ctx, uint64_t* d_bg) {
 
 int pengk_bg_model(pengk_ctx* ctx, const uint64_t* d_bg, int K, const float* h_alpha, float* d_V) {
   if (!ctx || !d_bg || !h_alpha || !d_V) return fail(PENGK_ERR_ARG, "pengk_bg_model: NULL argument");
+  PENGK_ENTER(ctx);
   if (K < 0 || K > 2) return fail(PENGK_ERR_ARG, "background order %d unsupported (0..2)", K);
   return launch_bg_model(ctx, d_bg, K, h_alpha, d_V);
 }
@@ -335,6 +376,7 @@ int pengk_pattern_stats(pengk_ctx* ctx, int W, int both, int k, int max_k, const
                         const uint32_t* d_counts, float* d_bgprob, float* d_expected, float* d_logp, float* d_z) {
   if (!ctx || !d_V || !d_ltot || !d_counts || !d_bgprob || !d_expected || !d_logp || !d_z)
     return fail(PENGK_ERR_ARG, "pengk_pattern_stats: NULL argument");
+  PENGK_ENTER(ctx);
   if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
   if (k < 0 || max_k > 2 || k > max_k || max_k > W - 1) return fail(PENGK_ERR_ARG, "background orders k=%d max_k=%d unsupported", k, max_k);
   return launch_stats(ctx, W, both ? 1 : 0, k, max_k, d_V, d_ltot, d_counts, d_bgprob, d_expected, d_logp, d_z);
@@ -344,6 +386,7 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids
                           const float* d_bgp, const float* d_expected, pengk_iupac_stats* h_out) {
   if (!ctx || (n && (!h_ids || !h_out)) || !d_counts || !d_bgp || !d_expected)
     return fail(PENGK_ERR_ARG, "pengk_iupac_aggregate: NULL argument");
+  PENGK_ENTER(ctx);
   if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
   if (n < 0) return fail(PENGK_ERR_ARG, "negative pattern count");
   if (n == 0) return PENGK_OK;
@@ -353,6 +396,7 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids
 int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
                     const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
   if (!ctx || !d_pwms || !d_counts || !d_bg || !d_state || !d_change) return fail(PENGK_ERR_ARG, "pengk_em_device: NULL argument");
+  PENGK_ENTER(ctx);
   if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
   if (n_pwm < 0 || max_it < 0) return fail(PENGK_ERR_ARG, "negative count");
   if (n_pwm == 0) return PENGK_OK;
@@ -362,6 +406,7 @@ int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float s
 int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturation, float threshold, int max_it,
              const uint32_t* d_counts, const float* d_bg, int* h_iters, float* h_change) {
   if (!ctx || (n_pwm && !h_pwms) || !d_counts || !d_bg) return fail(PENGK_ERR_ARG, "pengk_em: NULL argument");
+  PENGK_ENTER(ctx);
   if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
   if (n_pwm < 0 || max_it < 0) return fail(PENGK_ERR_ARG, "negative count");
   if (n_pwm == 0) return PENGK_OK;

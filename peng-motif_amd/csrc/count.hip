@@ -17,13 +17,9 @@
 // defer list and redone by count_fixup_kernel, which searches backwards for a certified start.
 #include <stdlib.h>
 
-#include "pengk_internal.h"
+#include <type_traits>
 
-#ifndef PENGK_ABLATE
-#define PENGK_ABLATE 0  // timing experiments (compile time, wrong results): 1 = never flush, 2 = no append at all,
-                        // 4 = no fused K1b, 8 = conflict-free bucket per lane, 16 = no LDS read in the flush,
-                        // 32 = no key store (tools/ablate.sh)
-#endif
+#include "pengk_internal.h"
 
 namespace pengk {
 
@@ -53,7 +49,8 @@ __device__ __forceinline__ uint32_t revcomp16(uint32_t x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The scan shared by both K1 variants.  `Emit` receives every COUNTED window: emit(can, active).
+// The scan shared by both K1 variants.  `Emit` receives every window's key: emit.full(key) from all lanes (key = INVALID_ID for a
+// suppressed window) or emit.masked(key, active).
 // It is called by all lanes of the wave in lock step (active = this lane has a counted window).
 // ---------------------------------------------------------------------------------------------
 // Fused K1b: while the scan rolls the id, the top three digits ARE the 3-mer ending at the current base.
@@ -61,8 +58,12 @@ __device__ __forceinline__ uint32_t revcomp16(uint32_t x) {
 // bases (counted in the prologue).  Bins live in LDS per wave: [0..63] 3-mers (little-endian digits),
 // [64..67] first base of a run, [68..83] first 2-mer (x0 | x1 << 2).  Only meaningful for inputs made
 // of whole sequences (pengk_packed.all_whole), where runs == sequences.
+// Full chunks (every lane owns all 16 window-end bases) count one 4-MER per two bases instead: the 4-mer ending on
+// base u holds the 3-mers ending on u-1 and on u, so bins4 is folded into the 3-mer bins at the end of the kernel
+// (one LDS add per two bases).
 struct BgLds {
   uint32_t bins[4][96];
+  uint32_t bins4[4][256];
 };
 __device__ __forceinline__ BgLds& bg_lds() {
   __shared__ BgLds sh;
@@ -72,7 +73,11 @@ template <int W, bool BG>
 struct BgCount {
   uint32_t wave;
   __device__ __forceinline__ void kmer3(uint32_t id, bool on) const {
-    if (BG && !(PENGK_ABLATE & 4)) atomicAdd(&bg_lds().bins[wave][on ? (id >> (2 * W - 6)) : 95u], 1u);  // bin 95: sink
+    if (BG) atomicAdd(&bg_lds().bins[wave][on ? (id >> (2 * W - 6)) : 95u], 1u);  // bin 95: sink
+  }
+  // 4-mer (first base in the low bits) ending on an owned base whose predecessor is owned too
+  __device__ __forceinline__ void kmer4(uint32_t v) const {
+    if (BG) atomicAdd(&bg_lds().bins4[wave][v], 1u);
   }
   // base at run position sp (static) of a non-continuing item, id already rolled
   __device__ __forceinline__ void head(uint32_t id, int sp, bool on) const {
@@ -87,6 +92,7 @@ template <bool BG>
 __device__ __forceinline__ void bg_begin() {
   if (BG) {
     for (uint32_t i = threadIdx.x; i < 4u * 96u; i += blockDim.x) (&bg_lds().bins[0][0])[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 4u * 256u; i += blockDim.x) (&bg_lds().bins4[0][0])[i] = 0;
   }
 }
 // block partials [gridDim.x][84]; summed in block order by bg_finish_fused_kernel (deterministic, no atomics)
@@ -96,11 +102,69 @@ __device__ __forceinline__ void bg_end(uint32_t* __restrict__ bg_partials) {
     __syncthreads();
     if (threadIdx.x < 84) {
       const BgLds& b = bg_lds();
-      bg_partials[(size_t)blockIdx.x * 84 + threadIdx.x] =
-          b.bins[0][threadIdx.x] + b.bins[1][threadIdx.x] + b.bins[2][threadIdx.x] + b.bins[3][threadIdx.x];
+      const uint32_t k = threadIdx.x;
+      uint32_t v = b.bins[0][k] + b.bins[1][k] + b.bins[2][k] + b.bins[3][k];
+      if (k < 64) {  // 4-mer v4 = b0 | b1 << 2 | b2 << 4 | b3 << 6 holds the 3-mers v4 & 63 and v4 >> 2
+        for (uint32_t w = 0; w < 4; ++w)
+          for (uint32_t c = 0; c < 4; ++c) v += b.bins4[w][k | (c << 6)] + b.bins4[w][(k << 2) | c];
+      }
+      bg_partials[(size_t)blockIdx.x * 84 + k] = v;
     }
   }
 }
+
+// "can equals one of the ids of the last W-1 COUNTED windows" (src/base_pattern.cpp:361-366 restated, see the file
+// header) as a chain of W-1 v_cmpx_ne_u32: every compare narrows EXEC to the lanes that have not matched yet, the
+// final v_mov runs only in those, and EXEC is restored -- W+1 vector instructions instead of the 2(W-1) of an
+// xor / min3 / compare / select chain (pass A of the partitioned count is bound by its VALU instruction count;
+// v_cmp_eq into SGPR pairs + s_or_b64 saturated the CU's one scalar ALU instead, profiles/r01_v3_pmc_sq.txt).
+// Returns can, or INVALID_ID for a suppressed window.  ring[(u - d) & 15] is the key of the window d positions back.
+template <int W>
+struct Suppress {
+  static __device__ __forceinline__ uint32_t apply(uint32_t can, const uint32_t (&ring)[16], int u) {
+    uint32_t out = INVALID_ID;
+    unsigned long long save;
+#define PENGK_R(d) "v"(ring[(u - (d)) & 15])
+#define PENGK_CX(n) "v_cmpx_ne_u32_e32 %2, %" #n "\n\t"
+#define PENGK_HEAD "s_mov_b64 %1, exec\n\t"
+#define PENGK_TAIL "v_mov_b32_e32 %0, %2\n\ts_mov_b64 exec, %1"
+    if constexpr (W == 4)
+      asm volatile(PENGK_HEAD PENGK_CX(3) PENGK_CX(4) PENGK_CX(5) PENGK_TAIL
+                   : "+v"(out), "=&s"(save) : "v"(can), PENGK_R(1), PENGK_R(2), PENGK_R(3) : "vcc");
+    else if constexpr (W == 6)
+      asm volatile(PENGK_HEAD PENGK_CX(3) PENGK_CX(4) PENGK_CX(5) PENGK_CX(6) PENGK_CX(7) PENGK_TAIL
+                   : "+v"(out), "=&s"(save) : "v"(can), PENGK_R(1), PENGK_R(2), PENGK_R(3), PENGK_R(4), PENGK_R(5) : "vcc");
+    else if constexpr (W == 8)
+      asm volatile(PENGK_HEAD PENGK_CX(3) PENGK_CX(4) PENGK_CX(5) PENGK_CX(6) PENGK_CX(7) PENGK_CX(8) PENGK_CX(9) PENGK_TAIL
+                   : "+v"(out), "=&s"(save)
+                   : "v"(can), PENGK_R(1), PENGK_R(2), PENGK_R(3), PENGK_R(4), PENGK_R(5), PENGK_R(6), PENGK_R(7) : "vcc");
+    else if constexpr (W == 10)
+      asm volatile(PENGK_HEAD PENGK_CX(3) PENGK_CX(4) PENGK_CX(5) PENGK_CX(6) PENGK_CX(7) PENGK_CX(8) PENGK_CX(9) PENGK_CX(10)
+                   PENGK_CX(11) PENGK_TAIL
+                   : "+v"(out), "=&s"(save)
+                   : "v"(can), PENGK_R(1), PENGK_R(2), PENGK_R(3), PENGK_R(4), PENGK_R(5), PENGK_R(6), PENGK_R(7), PENGK_R(8),
+                     PENGK_R(9) : "vcc");
+    else if constexpr (W == 12)
+      asm volatile(PENGK_HEAD PENGK_CX(3) PENGK_CX(4) PENGK_CX(5) PENGK_CX(6) PENGK_CX(7) PENGK_CX(8) PENGK_CX(9) PENGK_CX(10)
+                   PENGK_CX(11) PENGK_CX(12) PENGK_CX(13) PENGK_TAIL
+                   : "+v"(out), "=&s"(save)
+                   : "v"(can), PENGK_R(1), PENGK_R(2), PENGK_R(3), PENGK_R(4), PENGK_R(5), PENGK_R(6), PENGK_R(7), PENGK_R(8),
+                     PENGK_R(9), PENGK_R(10), PENGK_R(11) : "vcc");
+    else {
+      static_assert(W == 14, "pattern lengths 4 .. 14");
+      asm volatile(PENGK_HEAD PENGK_CX(3) PENGK_CX(4) PENGK_CX(5) PENGK_CX(6) PENGK_CX(7) PENGK_CX(8) PENGK_CX(9) PENGK_CX(10)
+                   PENGK_CX(11) PENGK_CX(12) PENGK_CX(13) PENGK_CX(14) PENGK_CX(15) PENGK_TAIL
+                   : "+v"(out), "=&s"(save)
+                   : "v"(can), PENGK_R(1), PENGK_R(2), PENGK_R(3), PENGK_R(4), PENGK_R(5), PENGK_R(6), PENGK_R(7), PENGK_R(8),
+                     PENGK_R(9), PENGK_R(10), PENGK_R(11), PENGK_R(12), PENGK_R(13) : "vcc");
+    }
+#undef PENGK_R
+#undef PENGK_CX
+#undef PENGK_HEAD
+#undef PENGK_TAIL
+    return out;
+  }
+};
 
 template <int W, bool BOTH, bool BG, class Emit>
 __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32, const uint64_t* __restrict__ items,
@@ -215,29 +279,40 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
         view[j] = funnel(chunk, pchunk, 2u * (uint32_t)(j * G::PER + 17 - W));
         rview[j] = BOTH ? funnel(rprev, rchunk, 2u * (uint32_t)(j * G::PER + 17 - W)) : 0u;
       }
+      // Two bodies.  FULL (wave-uniform: every lane owns all 16 windows of this chunk -- all chunks but the last of
+      // equally long items): no per-window range tests, suppressed windows travel as INVALID_ID keys, and the fused
+      // K1b counts one 4-mer per two bases.  Otherwise the per-window predicates decide.
+      auto body = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        uint32_t id_u, rc_u = 0;
-        if (u >= W - 1) {  // the window lies inside this chunk
-          id_u = __builtin_amdgcn_ubfe(chunk, 2u * (uint32_t)(u - (W - 1)), 2u * W);
-          if (BOTH) rc_u = __builtin_amdgcn_ubfe(rchunk, 2u * (uint32_t)(15 - u), 2u * W);
-        } else {
-          const int j = u / G::PER, k = W - 2 - u, jr = k / G::PER;
-          id_u = __builtin_amdgcn_ubfe(view[j], 2u * (uint32_t)(u - j * G::PER), 2u * W);
-          if (BOTH) rc_u = __builtin_amdgcn_ubfe(rview[jr], 2u * (uint32_t)(k - jr * G::PER), 2u * W);
+        for (int u = 0; u < 16; ++u) {
+          uint32_t id_u, rc_u = 0;
+          if (u >= W - 1) {  // the window lies inside this chunk
+            id_u = __builtin_amdgcn_ubfe(chunk, 2u * (uint32_t)(u - (W - 1)), 2u * W);
+            if (BOTH) rc_u = __builtin_amdgcn_ubfe(rchunk, 2u * (uint32_t)(15 - u), 2u * W);
+          } else {
+            const int j = u / G::PER, k = W - 2 - u, jr = k / G::PER;
+            id_u = __builtin_amdgcn_ubfe(view[j], 2u * (uint32_t)(u - j * G::PER), 2u * W);
+            if (BOTH) rc_u = __builtin_amdgcn_ubfe(rview[jr], 2u * (uint32_t)(k - jr * G::PER), 2u * W);
+          }
+          const uint32_t can = BOTH ? min(id_u, rc_u) : id_u;
+          const uint32_t key = Suppress<W>::apply(can, ring, u);  // INVALID_ID iff one of the last W-1 counted ids
+          ring[u] = key;
+          if (FULL) {
+            if (BG && (u & 1)) {  // 4-mer ending on base u: bases u-3 .. u
+              const uint32_t v4 = u >= 3 ? __builtin_amdgcn_ubfe(chunk, 2u * (uint32_t)(u - 3), 8u)
+                                         : funnel(chunk, pchunk, 2u * (uint32_t)(13 + u)) & 0xFFu;
+              bgc.kmer4(v4);
+            }
+            emit.full(key);
+          } else {
+            bgc.kmer3(id_u, t0 + (uint32_t)u < nw_all);
+            emit.masked(key, key != INVALID_ID && t0 + (uint32_t)u < nw);
+          }
         }
-        const uint32_t can = BOTH ? min(id_u, rc_u) : id_u;
-        // "can equals one of the last W-1 counted ids" as min over xors == 0: VALU only.  (The obvious
-        // v_cmp_eq chain costs 8 s_or_b64 per window and the kernel was bound by the CU's single scalar
-        // ALU: 42 SALU instructions per window, profiles/r01_v3_pmc_sq.txt.)
-        uint32_t diff = can ^ ring[(u - 1) & 15];
-#pragma unroll
-        for (int d = 2; d <= W - 1; ++d) diff = min(diff, can ^ ring[(u - d) & 15]);
-        const bool match = diff == 0u;
-        ring[u] = match ? INVALID_ID : can;
-        bgc.kmer3(id_u, t0 + (uint32_t)u < nw_all);
-        emit(can, !match && t0 + (uint32_t)u < nw);
-      }
+      };
+      if (__all((t0 + 16u <= nw && nw == nw_all) ? 1 : 0)) body(std::true_type{});
+      else body(std::false_type{});
       pchunk = chunk;
       rprev = rchunk;
     }
@@ -256,9 +331,10 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
 // ---------------------------------------------------------------------------------------------
 struct DirectEmit {
   uint32_t* __restrict__ hist;
-  __device__ __forceinline__ void operator()(uint32_t can, bool active) const {
-    if (active) __hip_atomic_fetch_add(&hist[can], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __device__ __forceinline__ void masked(uint32_t key, bool active) const {
+    if (active) __hip_atomic_fetch_add(&hist[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __device__ __forceinline__ void full(uint32_t key) const { masked(key, key != INVALID_ID); }
 };
 
 template <int W, bool BOTH, bool BG>
@@ -346,11 +422,17 @@ struct Split12L2 {
   }
 };
 
+// One row per (wave, bucket): the ring and, behind it, its counter.  The odd row stride (65 dwords) spreads rows over
+// the LDS banks: rings fill at the same pace, and with a 256-byte stride equal fill levels would put every lane of
+// the 16-bit ring write -- and every counter -- on the same few banks.
+struct ScatterRow {
+  uint16_t ring[RING_CAP];
+  uint32_t fill4;  // 4 x (keys ever appended to this (wave, bucket))
+};
 template <int NBITS>
 struct ScatterShared {
   static constexpr int NB = 1 << NBITS;
-  uint32_t ring[4][NB + 1][RING_CAP / 2];  // two 16-bit payloads per word; bucket NB is a sink for inactive lanes
-  uint32_t fill[4][NB + 1];
+  ScatterRow row[4][NB];
 };
 
 // The one LDS instance per workgroup.  It is reached through this accessor, never through a pointer
@@ -362,17 +444,22 @@ __device__ __forceinline__ ScatterShared<NBITS>& scatter_lds() {
   return sh;
 }
 
-// No cursor state at all: ring counters are LDS atomics that count every key ever appended to a (wave, bucket),
-// so the counter value a lane gets back IS the key's position in the slice -- the group that completes with slot
-// s goes to slice entries [s - 63, s], an address formed from wave-uniform scalars (SALU) plus lane * 2.  Ring
-// payloads written by other lanes are read with a wavefront-scope atomic load.  (Earlier versions kept a write
-// cursor per bucket in LDS words -- the compiler legally re-used stale copies -- and then in the registers of
-// lane b: three v_readlane, a 64-bit add and two selects per flush.)
+// No cursor state at all: a row's counter is an LDS atomic that counts every key ever appended to the (wave, bucket),
+// so the value a lane gets back IS the key's position in the slice -- the group that completes with slot s goes to
+// slice entries [s - 63, s], an address formed from wave-uniform scalars (SALU) plus lane * 2.  Ring payloads written
+// by other lanes are read through a volatile LDS pointer.  (Earlier versions kept a write cursor per bucket in LDS
+// words -- the compiler legally re-used stale copies -- and then in the registers of lane b: three v_readlane, a
+// 64-bit add and two selects per flush.)
+//
+// The counter advances by 4 per key: byte 0 of the returned value is then 4 * (slot mod 64), so "this key completes
+// a group" is ONE sub-dword compare, and (value >> 1) & 0xFF is the byte offset of the key's ring entry.  A
+// suppressed window arrives as INVALID_ID: its bucket bits select the last bucket and its payload bits are
+// KEY_INVALID, which pass B skips -- no select, no sink row (7 vector instructions per key instead of 14).
 template <class KS, int NBITS>
 struct ScatterEmit {
   static constexpr int NB = 1 << NBITS;
   static_assert(GROUP == 64, "a group is one 2-byte store per lane");
-  static_assert(2 * NB <= GROUP, "the start offsets 2*b must stay inside the first group");
+  static_assert(RING_CAP == 128, "byte 0 of the counter addresses the ring");
   typedef __attribute__((address_space(1))) uint16_t global_u16;
   uint16_t* __restrict__ keys;
   uint32_t slice_cap;  // entries per (wave, bucket) slice, multiple of 64; NB * slice_cap < 2^32
@@ -381,91 +468,89 @@ struct ScatterEmit {
   uint32_t wave, lane, wave_global;   // wave, wave_global: wave-uniform (readfirstlane'd by the caller)
   uint32_t outer;     // level-1 bucket these keys came from (two-level partition); 0 otherwise
 
-  // All threads of the workgroup, before the first barrier.  Counter b starts at 2*b, not 0: rings fill at the
-  // same pace, and with a row stride of 256 B equal fill levels would put every lane of the ds_write_b16 on the
-  // same few banks; the offset spreads them one bank apart at no cost per key.  The skipped entries are
-  // KEY_INVALID padding at the head of each slice (the whole ring starts as KEY_INVALID).
+  // All threads of the workgroup, before the first barrier: rings KEY_INVALID, counters 0.
   static __device__ __forceinline__ void init_lds() {
     ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
-    for (uint32_t i = threadIdx.x; i < 4u * (NB + 1u) * (RING_CAP / 2); i += blockDim.x) (&sh.ring[0][0][0])[i] = 0xFFFFFFFFu;
-    for (uint32_t i = threadIdx.x; i < 4u * (NB + 1u); i += blockDim.x) {
-      const uint32_t b = i % (NB + 1u);
-      (&sh.fill[0][0])[i] = b < (uint32_t)NB ? 2u * b : 0u;
-    }
+    static_assert(sizeof(ScatterRow) == 2 * RING_CAP + 4, "row = ring + counter");
+    uint32_t* w = reinterpret_cast<uint32_t*>(&sh.row[0][0]);
+    for (uint32_t i = threadIdx.x; i < 4u * NB * (sizeof(ScatterRow) / 4u); i += blockDim.x)
+      w[i] = (i % (uint32_t)(sizeof(ScatterRow) / 4u)) == (uint32_t)(RING_CAP / 2) ? 0u : 0xFFFFFFFFu;
   }
 
   // A completed group (64 ring entries from slot g0, a multiple of 64) goes to slice entries [g0, g0 + 64) as ONE
   // 128-byte line, one 2-byte store per lane (PARTIAL: entries >= nvalid become KEY_INVALID).  b, g0 and nvalid
-  // are wave-uniform.  (Splitting this into "read now, store in the next call" and really overlapping the slot
-  // atomic with the next window's scan were both built and measured: no gain -- the kernel is bound by the LDS
-  // pipeline, other waves already cover the latencies.)
-  __device__ __forceinline__ uint32_t read_group(uint32_t b, uint32_t g0) const {
-    typedef const volatile __attribute__((address_space(3))) uint16_t lds_u16;  // a generic pointer would become a flat load
-    lds_u16* ring16 = (lds_u16*)&scatter_lds<NBITS>().ring[wave][b][0];
-    return (PENGK_ABLATE & 16) ? lane  // experiment: no LDS read in the flush
-                               : (uint32_t)ring16[(g0 & (uint32_t)(RING_CAP - 1)) + lane];
-  }
-  __device__ __forceinline__ void store_line(uint32_t off, uint32_t v) const {
-    // explicit global address space (a flat store would stall LDS waits); scalar base + lane * 2
-    global_u16* dst = (global_u16*)(keys + ((size_t)wave_global * NB * slice_cap + (size_t)off));
-    if (!(PENGK_ABLATE & 32)) __builtin_nontemporal_store((uint16_t)v, &dst[lane]);  // written once, read once by pass B
-  }
+  // are wave-uniform.
   template <bool PARTIAL>
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
-    uint32_t v = read_group(b, g0);
+    typedef const volatile __attribute__((address_space(3))) uint16_t lds_u16;  // a generic pointer would become a flat load
+    lds_u16* ring16 = (lds_u16*)&scatter_lds<NBITS>().row[wave][b].ring[0];
+    uint32_t v = (uint32_t)ring16[(g0 & (uint32_t)(RING_CAP - 1)) + lane];
     if (PARTIAL && lane >= nvalid) v = KEY_INVALID;
-    if (g0 + (uint32_t)GROUP <= slice_cap)  // wave-uniform
-      store_line(b * slice_cap + g0, v);
-    else if (v != KEY_INVALID)  // slice full: count these windows directly (rare; skewed inputs)
+    if (g0 + (uint32_t)GROUP <= slice_cap) {  // wave-uniform
+      // explicit global address space (a flat store would stall LDS waits); scalar base + lane * 2
+      global_u16* dst = (global_u16*)(keys + ((size_t)wave_global * NB * slice_cap + (size_t)(b * slice_cap + g0)));
+      __builtin_nontemporal_store((uint16_t)v, &dst[lane]);  // written once, read once by pass B
+    } else if (v != KEY_INVALID) {  // slice full: count these windows directly (rare; skewed inputs)
       __hip_atomic_fetch_add(&hist[KS::join(b, v, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 
-  // The append is split over two calls: a call first completes the PREVIOUS key (ring write, group-complete
-  // check, flush) and then issues the LDS atomic for the current one.
-  // Inactive lanes append to the sink bucket NB; its "groups" are never written anywhere.
-  uint32_t p_slot = 0, p_b = NB, p_payload = 0;
-
-  __device__ __forceinline__ void finish_pending() {
-    ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
-    // u16 index (bucket << 7) | (slot & 127) inside the wave's rings: and, shift-or, shift-add
-    static_assert(RING_CAP == 128, "ring rows are 128 u16 entries");
-    reinterpret_cast<uint16_t*>(&sh.ring[wave][0][0])[(p_b << 7) | (p_slot & (uint32_t)(RING_CAP - 1))] = (uint16_t)p_payload;
-    unsigned long long trig = __builtin_amdgcn_ballot_w64((p_slot & (uint32_t)(GROUP - 1)) == (uint32_t)(GROUP - 1));
-    if (PENGK_ABLATE & 1) trig = 0;
+  __device__ __forceinline__ void flush_triggered(unsigned long long trig, uint32_t b, uint32_t s4) {
     while (trig) {  // wave-uniform: a ring just completed a group of 64 (on average one per call)
       const int src = __builtin_ctzll(trig);
       trig &= trig - 1;
-      const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)p_b, src);
-      const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)p_slot, src);
-      if (fb == (uint32_t)NB) continue;
+      const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
+      const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)s4, src) >> 2;
       __builtin_amdgcn_wave_barrier();
       flush_group<false>(fb, fs - (uint32_t)(GROUP - 1), (uint32_t)GROUP);
     }
   }
 
-  __device__ __forceinline__ void operator()(uint32_t can, bool active) {
-    if (PENGK_ABLATE & 2) return;
-    __builtin_amdgcn_sched_barrier(0);
-    finish_pending();  // (the first call completes a dummy append to the sink bucket)
-    p_b = active ? KS::bucket(can) : (uint32_t)NB;  // every lane appends; inactive ones to the sink
-    if (PENGK_ABLATE & 8) p_b = lane & (uint32_t)(NB - 1);  // experiment: conflict-free counter addresses
-    p_payload = KS::payload(can);
-    p_slot = atomicAdd(&scatter_lds<NBITS>().fill[wave][p_b], 1u);
+  // LDS byte address of this wave's row 0, held in a VECTOR register on purpose (opaque to the compiler): the row
+  // address is then one v_mad_u32_u24 (a VALU instruction reads at most one scalar operand on gfx950, and the
+  // compiler otherwise re-materialises the scalar base with a v_mov per key).
+  uint32_t rowbase = 0;
+  __device__ __forceinline__ void bind() {
+    rowbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&scatter_lds<NBITS>().row[wave][0];
+    asm volatile("" : "+v"(rowbase));
+  }
+  typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+  typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+
+  // append one key per lane; returns 4 x slot
+  __device__ __forceinline__ uint32_t append(uint32_t b, uint32_t key) const {
+    const uint32_t row = b * (uint32_t)sizeof(ScatterRow) + rowbase;  // b < NB: one v_mad_u32_u24
+    const uint32_t s4 = __hip_atomic_fetch_add((lds_u32_t*)(uintptr_t)(row + 2u * RING_CAP), 4u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    *(lds_u16_t*)(uintptr_t)(row + ((s4 >> 1) & 0xFFu)) = (uint16_t)KS::payload(key);
+    return s4;
+  }
+
+  // every lane appends; key may be INVALID_ID (or any value whose payload bits are all ones)
+  __device__ __forceinline__ void full(uint32_t key) {
+    const uint32_t b = KS::bucket(key);
+    const uint32_t s4 = append(b, key);
+    flush_triggered(__builtin_amdgcn_ballot_w64((s4 & 0xFFu) == 4u * (uint32_t)(GROUP - 1)), b, s4);
+  }
+
+  // only the lanes with `active` append
+  __device__ __forceinline__ void masked(uint32_t key, bool active) {
+    const uint32_t b = KS::bucket(key);
+    uint32_t s4 = 0;
+    if (active) s4 = append(b, key);
+    flush_triggered(__builtin_amdgcn_ballot_w64(active && (s4 & 0xFFu) == 4u * (uint32_t)(GROUP - 1)), b, s4);
   }
 
   // end of kernel: partial groups, then publish how much of each slice is filled
   __device__ __forceinline__ void drain() {
-    finish_pending();
-    p_b = NB;
-    p_slot = 0;
     __builtin_amdgcn_wave_barrier();
     for (uint32_t b = 0; b < (uint32_t)NB; ++b) {
-      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().fill[wave][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().row[wave][b].fill4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 2;
       const uint32_t r = f & (uint32_t)(GROUP - 1);
       if (r) flush_group<true>(b, f & ~(uint32_t)(GROUP - 1), r);
     }
     if (lane < (uint32_t)NB) {
-      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().fill[wave][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().row[wave][lane].fill4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 2;
       const uint32_t full = (f + (uint32_t)(GROUP - 1)) & ~(uint32_t)(GROUP - 1);
       slice_fill[(size_t)wave_global * NB + lane] = full < slice_cap ? full : slice_cap;
     }
@@ -486,6 +571,7 @@ __global__ __launch_bounds__(256) void count_scatter_kernel(const uint32_t* __re
   __syncthreads();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   ScatterEmit<KeySplit<W, NBITS>, NBITS> e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * 4u + wave, 0u};
+  e.bind();
   scan_items<W, BOTH, BG>(words32, items, n_items, ltot, defer, e);
   e.drain();
   bg_end<BG>(bg_partials);
@@ -540,21 +626,36 @@ struct Scatter32Emit {
     }
   }
 
-  __device__ __forceinline__ void operator()(uint32_t can, bool active) {
+  // A ring holds RING32_CAP = 64 entries and leaves in groups of 32, so at most 31 unflushed keys wait in it.
+  // The wave appends in two half-waves (lanes 0-31, flush what completed, lanes 32-63): a single call can then add
+  // at most 32 keys to one ring before the next flush, 31 + 32 < 64, and no unflushed entry is ever overwritten --
+  // even when all 64 lanes of a step hit one bucket (adjacent identical sequences, poly-T on the plus strand).
+  static_assert(RING32_CAP >= GROUP32 - 1 + 32 + 1, "a half-wave append must fit behind the unflushed rest");
+  __device__ __forceinline__ void full(uint32_t key) { masked(key, key != INVALID_ID); }
+  __device__ __forceinline__ void masked(uint32_t can, bool active) {
     const uint32_t b = active ? Split12L1::bucket(can) : 32u;  // inactive lanes: sink bucket, never flushed
+    const uint32_t payload = Split12L1::payload(can);
     Scatter32Shared& sh = scatter32_lds();
-    const uint32_t slot = atomicAdd(&sh.fill[wave][b], 1u);
-    (&sh.ring[wave][0][0])[(b << 6) | (slot & (uint32_t)(RING32_CAP - 1))] = Split12L1::payload(can);
     static_assert(RING32_CAP == 64, "ring rows are 64 entries");
-    unsigned long long trig = __builtin_amdgcn_ballot_w64((slot & (uint32_t)(GROUP32 - 1)) == (uint32_t)(GROUP32 - 1));
-    while (trig) {
-      const int src = __builtin_ctzll(trig);
-      trig &= trig - 1;
-      const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
-      const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)slot, src);
-      if (fb == 32u) continue;
+#pragma unroll
+    for (uint32_t half = 0; half < 2u; ++half) {
+      const bool mine = (lane >> 5) == half;
+      uint32_t slot = 0;
+      if (mine) {
+        slot = atomicAdd(&sh.fill[wave][b], 1u);
+        (&sh.ring[wave][0][0])[(b << 6) | (slot & (uint32_t)(RING32_CAP - 1))] = payload;
+      }
+      unsigned long long trig = __builtin_amdgcn_ballot_w64(mine && (slot & (uint32_t)(GROUP32 - 1)) == (uint32_t)(GROUP32 - 1));
+      while (trig) {
+        const int src = __builtin_ctzll(trig);
+        trig &= trig - 1;
+        const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
+        const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)slot, src);
+        if (fb == 32u) continue;
+        __builtin_amdgcn_wave_barrier();
+        flush_group(fb, fs - (uint32_t)(GROUP32 - 1), (uint32_t)GROUP32);
+      }
       __builtin_amdgcn_wave_barrier();
-      flush_group(fb, fs - (uint32_t)(GROUP32 - 1), (uint32_t)GROUP32);
     }
   }
 
@@ -602,6 +703,7 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
   const uint32_t b1 = blockIdx.x / bpb1, j = blockIdx.x % bpb1;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
   ScatterEmit<Split12L2, 4> e{keys2, cap2, fill2, hist, wave, lane, blockIdx.x * 4u + wave, b1};
+  e.bind();
   const uint32_t per = (n_slices1 + bpb1 - 1) / bpb1;
   const uint32_t first = j * per, last = min(n_slices1, first + per);
   for (uint32_t s = first + wave; s < last; s += 4) {
@@ -609,7 +711,7 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
     const uint32_t* src = keys1 + ((size_t)s * 32u + b1) * cap1;
     for (uint32_t i = 0; i < n; i += 64) {  // wave-uniform trip count
       const uint32_t k = (i + lane < n) ? __builtin_nontemporal_load(&src[i + lane]) : KEY32_INVALID;
-      e(k, k != KEY32_INVALID);
+      e.masked(k, k != KEY32_INVALID);
     }
   }
   e.drain();
@@ -1007,8 +1109,7 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
   // grid of pass A: LDS (33 KiB per block at NB = 32) admits 4 blocks per CU
   const uint32_t blocks_needed = (n_items + 255) / 256;
-  uint32_t per_cu = 4u;
-  if (const char* e = getenv("PENGK_SCATTER_BLOCKS_PER_CU")) per_cu = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : per_cu;  // experiments
+  const uint32_t per_cu = ctx->scatter_blocks_per_cu ? (uint32_t)ctx->scatter_blocks_per_cu : 4u;
   const uint32_t max_blocks = (uint32_t)ctx->num_cu * per_cu;
   const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
   const uint32_t n_waves = blocks * 4u;
@@ -1047,11 +1148,6 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
     if (rc) return rc;
   }
   // pass B: one 1024-thread workgroup per CU (128 KiB of LDS), bpb workgroups per bucket
-  static bool attr_set = false;
-  if (!attr_set) {
-    PENGK_HIP(hipFuncSetAttribute((const void*)count_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << PAYLOAD_BITS));
-    attr_set = true;
-  }
   uint32_t bpb = ((uint32_t)ctx->num_cu * 2u + NB - 1) / NB;
   const uint64_t per_bucket = windows / NB + 1;
   const uint32_t useful = (uint32_t)((per_bucket + 65535) / 65536);  // >= 64 Ki keys per workgroup or it is not worth a block
@@ -1125,11 +1221,6 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   hipLaunchKernelGGL(count_rescatter12_kernel, dim3(blocks2), dim3(256), 0, ctx->stream, keys1, cap1, fill1, n_waves1, bpb1, keys2,
                      cap2, fill2, d_counts);
   PENGK_HIP(hipGetLastError());
-  static bool attr_set = false;
-  if (!attr_set) {
-    PENGK_HIP(hipFuncSetAttribute((const void*)count_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << PAYLOAD_BITS));
-    attr_set = true;
-  }
   hipLaunchKernelGGL(count_hist_kernel, dim3(512), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys2, cap2, n_waves2, 16u, fill2, 1u,
                      temp, bpb1 * 4u);
   PENGK_HIP(hipGetLastError());
@@ -1167,6 +1258,12 @@ int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_lto
 }
 
 }  // namespace
+
+// hipFuncSetAttribute applies to the CURRENT device: called from pengk_create after hipSetDevice, once per context
+int count_init_device() {
+  PENGK_HIP(hipFuncSetAttribute((const void*)count_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << PAYLOAD_BITS));
+  return PENGK_OK;
+}
 
 int launch_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg) {
   const int W = ctx->W;

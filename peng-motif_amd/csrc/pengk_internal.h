@@ -41,6 +41,7 @@ struct pengk_ctx {
   uint64_t iupac_group_bytes = 0; // test hook: scratch budget of one group of large K4 patterns (0 = 1 GiB)
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms
+  int scatter_blocks_per_cu = 0; // tuning hook: workgroups per CU of the partitioned scan (0 = default)
 };
 
 namespace pengk {
@@ -48,6 +49,8 @@ namespace pengk {
 int fail(int code, const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 int ensure_scratch(pengk_ctx* ctx, void** slot, size_t* have, size_t need);
+int enter(pengk_ctx* ctx);      // hipSetDevice(ctx->device)
+int count_init_device();        // per-device kernel attributes of count.hip (current device)
 
 #define PENGK_HIP(call)                                   \
   do {                                                    \

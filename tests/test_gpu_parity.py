@@ -190,6 +190,48 @@ def test_w12_two_level_partition(ctx, both):
         ctx.set_option("count_impl", 0)
 
 
+def _same_bucket_sets(W, L=120):
+    """Inputs that put many lanes of one wave on ONE partition bucket in the same step: the lanes of a wave hold
+    consecutive scan items, so adjacent identical sequences make them emit identical keys."""
+    rng = np.random.default_rng(12)
+    unit13 = rng.integers(1, 5, size=13).astype(np.uint8)  # period 13 > W - 1: every window is counted
+    rep13 = np.tile(unit13, L // 13 + 1)[:L]
+    poly_t = np.full(L, 4, np.uint8)
+    one = rng.integers(1, 5, size=L).astype(np.uint8)
+    sets = {}
+    sets["period13_x4000"] = np.tile(rep13, 4000)
+    sets["polyT_x4000"] = np.tile(poly_t, 4000)
+    sets["identical_random_x4000"] = np.tile(one, 4000)
+    mixed = []
+    for w in range(60):  # 64 sequences per wave: 40 copies of one sequence + 24 random ones
+        mixed.append(np.tile(rng.integers(1, 5, size=L).astype(np.uint8), 40))
+        mixed.append(rng.integers(1, 5, size=24 * L).astype(np.uint8))
+    sets["40_identical_24_random_per_wave"] = np.concatenate(mixed)
+    return {k: (v, np.arange(len(v) // L + 1, dtype=np.int64) * L) for k, v in sets.items()}
+
+
+@pytest.mark.parametrize("both", [True, False])
+@pytest.mark.parametrize("W", [12, 10, 8])
+def test_partitioned_count_many_lanes_on_one_bucket(ctx, W, both):
+    """All 64 lanes of a wave appending to one (wave, bucket) ring in a single step must not overwrite unflushed
+    ring entries (W = 12 level 1: 64-entry rings, groups of 32 -- the append runs in two half-waves; 16-bit rings:
+    128 entries, groups of 64).  ltot alone would not notice: the bins are compared with the oracle."""
+    for name, (codes, offs) in _same_bucket_sets(W).items():
+        want, ltot = po.count(codes, offs, W, both)
+        p = pk.Packed(codes, offs, W)
+        ctx.upload(p)
+        ctx.set_option("count_impl", 2)
+        try:
+            counts, lt = ctx.count(both)
+            if both:
+                ctx.mirror(W, counts)
+            assert int(lt.to_host()[0]) == ltot, name
+            got = counts.to_host().astype(np.uint64)
+            assert np.array_equal(got, want), "%s: %d mismatching bins" % (name, int((got != want).sum()))
+        finally:
+            ctx.set_option("count_impl", 0)
+
+
 def test_partitioned_count_survives_a_full_bucket_region(ctx):
     """Skew: every counted window lands in few buckets and the key-buffer hint is far too small, so bucket
     regions run full and the overflow path (direct atomics) must keep the table exact."""
