@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpengk.so")
+# PENGK_LIB: A/B timing of library variants in one session (tools/ab.sh); the product loads the in-tree build
+LIB_PATH = os.environ.get("PENGK_LIB") or os.path.join(_HERE, "libpengk.so")
 _lib = None
 
 PENGK_OK = 0

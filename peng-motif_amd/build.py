@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libpengk.so")
+LIB = os.environ.get("PENGK_BUILD_OUT") or os.path.join(HERE, "libpengk.so")  # PENGK_BUILD_OUT: variant builds for tools/ab.sh
 SOURCES = ["api.hip", "count.hip", "stats.hip", "iupac.hip", "em.hip", "pack.cpp"]
 HEADERS = [os.path.join(CSRC, "pengk_internal.h"), os.path.join(ROOT, "include", "pengk.h")]
 # -ffp-contract=off: float32 arithmetic must round exactly like the reference's scalar x86 code.
@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
         return LIB
     objs = []
     procs = []
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build") if not os.environ.get("PENGK_BUILD_OUT") else LIB + ".obj"
     os.makedirs(objdir, exist_ok=True)
     for s in SOURCES:
         o = os.path.join(objdir, s + ".o")

@@ -62,8 +62,8 @@ __device__ __forceinline__ uint32_t revcomp16(uint32_t x) {
 // base u holds the 3-mers ending on u-1 and on u, so bins4 is folded into the 3-mer bins at the end of the kernel
 // (one LDS add per two bases).
 struct BgLds {
-  uint32_t bins[4][96];
-  uint32_t bins4[4][256];
+  uint32_t bins[96];
+  uint32_t bins4[256];
 };
 __device__ __forceinline__ BgLds& bg_lds() {
   __shared__ BgLds sh;
@@ -73,26 +73,26 @@ template <int W, bool BG>
 struct BgCount {
   uint32_t wave;
   __device__ __forceinline__ void kmer3(uint32_t id, bool on) const {
-    if (BG) atomicAdd(&bg_lds().bins[wave][on ? (id >> (2 * W - 6)) : 95u], 1u);  // bin 95: sink
+    if (BG) atomicAdd(&bg_lds().bins[on ? (id >> (2 * W - 6)) : 95u], 1u);  // bin 95: sink
   }
   // 4-mer (first base in the low bits) ending on an owned base whose predecessor is owned too
   __device__ __forceinline__ void kmer4(uint32_t v) const {
-    if (BG) atomicAdd(&bg_lds().bins4[wave][v], 1u);
+    if (BG) atomicAdd(&bg_lds().bins4[v], 1u);
   }
   // base at run position sp (static) of a non-continuing item, id already rolled
   __device__ __forceinline__ void head(uint32_t id, int sp, bool on) const {
     if (!BG || !on || sp < 0) return;
-    if (sp == 0) atomicAdd(&bg_lds().bins[wave][64 + (id >> (2 * W - 2))], 1u);
-    else if (sp == 1) atomicAdd(&bg_lds().bins[wave][68 + (id >> (2 * W - 4))], 1u);
-    else atomicAdd(&bg_lds().bins[wave][id >> (2 * W - 6)], 1u);
+    if (sp == 0) atomicAdd(&bg_lds().bins[64 + (id >> (2 * W - 2))], 1u);
+    else if (sp == 1) atomicAdd(&bg_lds().bins[68 + (id >> (2 * W - 4))], 1u);
+    else atomicAdd(&bg_lds().bins[id >> (2 * W - 6)], 1u);
   }
 };
 
 template <bool BG>
 __device__ __forceinline__ void bg_begin() {
   if (BG) {
-    for (uint32_t i = threadIdx.x; i < 4u * 96u; i += blockDim.x) (&bg_lds().bins[0][0])[i] = 0;
-    for (uint32_t i = threadIdx.x; i < 4u * 256u; i += blockDim.x) (&bg_lds().bins4[0][0])[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 96u; i += blockDim.x) bg_lds().bins[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) bg_lds().bins4[i] = 0;
   }
 }
 // block partials [gridDim.x][84]; summed in block order by bg_finish_fused_kernel (deterministic, no atomics)
@@ -103,10 +103,9 @@ __device__ __forceinline__ void bg_end(uint32_t* __restrict__ bg_partials) {
     if (threadIdx.x < 84) {
       const BgLds& b = bg_lds();
       const uint32_t k = threadIdx.x;
-      uint32_t v = b.bins[0][k] + b.bins[1][k] + b.bins[2][k] + b.bins[3][k];
+      uint32_t v = b.bins[k];
       if (k < 64) {  // 4-mer v4 = b0 | b1 << 2 | b2 << 4 | b3 << 6 holds the 3-mers v4 & 63 and v4 >> 2
-        for (uint32_t w = 0; w < 4; ++w)
-          for (uint32_t c = 0; c < 4; ++c) v += b.bins4[w][k | (c << 6)] + b.bins4[w][(k << 2) | c];
+        for (uint32_t c = 0; c < 4; ++c) v += b.bins4[k | (c << 6)] + b.bins4[(k << 2) | c];
       }
       bg_partials[(size_t)blockIdx.x * 84 + k] = v;
     }
@@ -429,18 +428,18 @@ struct ScatterRow {
   uint16_t ring[RING_CAP];
   uint32_t fill4;  // 4 x (keys ever appended to this (wave, bucket))
 };
-template <int NBITS>
+template <int NBITS, int WPW>
 struct ScatterShared {
   static constexpr int NB = 1 << NBITS;
-  ScatterRow row[4][NB];
+  ScatterRow row[WPW][NB];
 };
 
 // The one LDS instance per workgroup.  It is reached through this accessor, never through a pointer
 // stored in a struct: a generic pointer made the compiler emit flat_load for the ring reads, and a flat
 // access waits for vmcnt(0) -- i.e. for every key store still in flight -- on every flush.
-template <int NBITS>
-__device__ __forceinline__ ScatterShared<NBITS>& scatter_lds() {
-  __shared__ ScatterShared<NBITS> sh;
+template <int NBITS, int WPW>
+__device__ __forceinline__ ScatterShared<NBITS, WPW>& scatter_lds() {
+  __shared__ ScatterShared<NBITS, WPW> sh;
   return sh;
 }
 
@@ -455,7 +454,7 @@ __device__ __forceinline__ ScatterShared<NBITS>& scatter_lds() {
 // a group" is ONE sub-dword compare, and (value >> 1) & 0xFF is the byte offset of the key's ring entry.  A
 // suppressed window arrives as INVALID_ID: its bucket bits select the last bucket and its payload bits are
 // KEY_INVALID, which pass B skips -- no select, no sink row (7 vector instructions per key instead of 14).
-template <class KS, int NBITS>
+template <class KS, int NBITS, int WPW = 4>
 struct ScatterEmit {
   static constexpr int NB = 1 << NBITS;
   static_assert(GROUP == 64, "a group is one 2-byte store per lane");
@@ -470,10 +469,10 @@ struct ScatterEmit {
 
   // All threads of the workgroup, before the first barrier: rings KEY_INVALID, counters 0.
   static __device__ __forceinline__ void init_lds() {
-    ScatterShared<NBITS>& sh = scatter_lds<NBITS>();
+    ScatterShared<NBITS, WPW>& sh = scatter_lds<NBITS, WPW>();
     static_assert(sizeof(ScatterRow) == 2 * RING_CAP + 4, "row = ring + counter");
     uint32_t* w = reinterpret_cast<uint32_t*>(&sh.row[0][0]);
-    for (uint32_t i = threadIdx.x; i < 4u * NB * (sizeof(ScatterRow) / 4u); i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)WPW * NB * (sizeof(ScatterRow) / 4u); i += blockDim.x)
       w[i] = (i % (uint32_t)(sizeof(ScatterRow) / 4u)) == (uint32_t)(RING_CAP / 2) ? 0u : 0xFFFFFFFFu;
   }
 
@@ -483,7 +482,7 @@ struct ScatterEmit {
   template <bool PARTIAL>
   __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
     typedef const volatile __attribute__((address_space(3))) uint16_t lds_u16;  // a generic pointer would become a flat load
-    lds_u16* ring16 = (lds_u16*)&scatter_lds<NBITS>().row[wave][b].ring[0];
+    lds_u16* ring16 = (lds_u16*)&scatter_lds<NBITS, WPW>().row[wave][b].ring[0];
     uint32_t v = (uint32_t)ring16[(g0 & (uint32_t)(RING_CAP - 1)) + lane];
     if (PARTIAL && lane >= nvalid) v = KEY_INVALID;
     if (g0 + (uint32_t)GROUP <= slice_cap) {  // wave-uniform
@@ -511,7 +510,7 @@ struct ScatterEmit {
   // compiler otherwise re-materialises the scalar base with a v_mov per key).
   uint32_t rowbase = 0;
   __device__ __forceinline__ void bind() {
-    rowbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&scatter_lds<NBITS>().row[wave][0];
+    rowbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&scatter_lds<NBITS, WPW>().row[wave][0];
     asm volatile("" : "+v"(rowbase));
   }
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
@@ -545,20 +544,24 @@ struct ScatterEmit {
   __device__ __forceinline__ void drain() {
     __builtin_amdgcn_wave_barrier();
     for (uint32_t b = 0; b < (uint32_t)NB; ++b) {
-      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().row[wave][b].fill4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 2;
+      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS, WPW>().row[wave][b].fill4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 2;
       const uint32_t r = f & (uint32_t)(GROUP - 1);
       if (r) flush_group<true>(b, f & ~(uint32_t)(GROUP - 1), r);
     }
     if (lane < (uint32_t)NB) {
-      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS>().row[wave][lane].fill4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 2;
+      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS, WPW>().row[wave][lane].fill4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 2;
       const uint32_t full = (f + (uint32_t)(GROUP - 1)) & ~(uint32_t)(GROUP - 1);
       slice_fill[(size_t)wave_global * NB + lane] = full < slice_cap ? full : slice_cap;
     }
   }
 };
 
+#ifndef PENGK_SCATTER_WPW
+#define PENGK_SCATTER_WPW 4
+#endif
+constexpr int SCATTER_WPW = PENGK_SCATTER_WPW;  // waves per workgroup of pass A
 template <int W, bool BOTH, int NBITS, bool BG>
-__global__ __launch_bounds__(256) void count_scatter_kernel(const uint32_t* __restrict__ words32,
+__global__ __launch_bounds__(64 * SCATTER_WPW) void count_scatter_kernel(const uint32_t* __restrict__ words32,
                                                             const uint64_t* __restrict__ items, uint32_t n_items,
                                                             uint16_t* __restrict__ keys, uint32_t slice_cap,
                                                             uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
@@ -566,11 +569,11 @@ __global__ __launch_bounds__(256) void count_scatter_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ defer,
                                                             uint32_t* __restrict__ bg_partials) {
   static_assert(2 * W - NBITS == PAYLOAD_BITS, "payload must be 15 bits");
-  ScatterEmit<KeySplit<W, NBITS>, NBITS>::init_lds();
+  ScatterEmit<KeySplit<W, NBITS>, NBITS, SCATTER_WPW>::init_lds();
   bg_begin<BG>();
   __syncthreads();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  ScatterEmit<KeySplit<W, NBITS>, NBITS> e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * 4u + wave, 0u};
+  ScatterEmit<KeySplit<W, NBITS>, NBITS, SCATTER_WPW> e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * (uint32_t)SCATTER_WPW + wave, 0u};
   e.bind();
   scan_items<W, BOTH, BG>(words32, items, n_items, ltot, defer, e);
   e.drain();
@@ -1107,12 +1110,14 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   constexpr uint32_t NB = 1u << NBITS;
   const uint32_t np = 1u << (2 * W);
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
-  // grid of pass A: LDS (33 KiB per block at NB = 32) admits 4 blocks per CU
-  const uint32_t blocks_needed = (n_items + 255) / 256;
-  const uint32_t per_cu = ctx->scatter_blocks_per_cu ? (uint32_t)ctx->scatter_blocks_per_cu : 4u;
+  // grid of pass A: as many workgroups per CU as the LDS admits (8.3 KiB of rings per wave at NB = 32)
+  constexpr uint32_t TPB = 64u * SCATTER_WPW;
+  const uint32_t blocks_needed = (n_items + TPB - 1) / TPB;
+  constexpr uint32_t lds_per_wg = (uint32_t)(sizeof(ScatterShared<NBITS, SCATTER_WPW>) + sizeof(BgLds) + 511u) & ~511u;
+  const uint32_t per_cu = ctx->scatter_blocks_per_cu ? (uint32_t)ctx->scatter_blocks_per_cu : (160u * 1024u) / lds_per_wg;
   const uint32_t max_blocks = (uint32_t)ctx->num_cu * per_cu;
   const uint32_t blocks = blocks_needed < max_blocks ? blocks_needed : max_blocks;
-  const uint32_t n_waves = blocks * 4u;
+  const uint32_t n_waves = blocks * (uint32_t)SCATTER_WPW;
   // static slices region[wave][bucket]: expected share + 50 % + slack, in groups of 64 entries
   uint64_t windows = ctx->n_windows_hint ? ctx->n_windows_hint : ctx->n_items * (uint64_t)ctx->item_windows;
   const uint64_t share = windows / ((uint64_t)NB * n_waves);
@@ -1139,7 +1144,7 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
     if (rc) return rc;
   }
 #define TA_SCATTER(B, G) W, B, NBITS, G
-  PENGK_LAUNCH_BB(count_scatter_kernel, TA_SCATTER, both, d_bg != nullptr, dim3(blocks), dim3(256), w32, ctx->d_items, n_items,
+  PENGK_LAUNCH_BB(count_scatter_kernel, TA_SCATTER, both, d_bg != nullptr, dim3(blocks), dim3(TPB), w32, ctx->d_items, n_items,
                   keys, slice_cap, slice_fill, d_counts, lt, ctx->d_defer, bgp);
 #undef TA_SCATTER
   PENGK_HIP(hipGetLastError());
