@@ -267,8 +267,8 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 // arithmetic for reverse-complement twins, so the last bits of those sums decide what the program prints.
 // A cell's sum is inherently sequential, but cells and PWMs are independent and the weights are not:
 //   em_weights_kernel  all weights w(x) of a PWM in parallel (reference float operations), to a scratch table;
-//   em_fold_kernel     two waves per PWM, one lane per cell (p, a): the lane walks ITS terms -- the x whose digit p
-//                      is a, ascending -- with the next group of loads in flight while it adds the current one.
+//   em_fold_kernel     one workgroup per position and PWM: the four cells (p, a) walk THEIR terms -- the x whose digit
+//                      p is a, ascending -- from LDS, where loader waves stage them with coalesced loads.
 // ---------------------------------------------------------------------------------------------
 template <int W>
 __global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
@@ -290,88 +290,135 @@ __global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict
   }
 }
 
-// Two waves per PWM.  Wave 0: the cells of positions p >= 1 -- their terms come in aligned groups of four consecutive x,
-// one 16-byte load per group (a dword load per term costs one cache-line request per lane and term: 40 requests per
-// instruction made the first version of this kernel 3.8 ms per iteration at W = 10).  Wave 1: the four cells of position
-// 0, whose terms are every fourth x: lanes 0..3 read the same 16 bytes and take one component each.
+// One workgroup per (position p, PWM): the four cells (p, a) of a position partition the table -- every x has exactly
+// one digit at position p -- so the workgroup streams each cell's terms, in the cell's order, through LDS:
+//   waves 1, 2  (loaders) fetch chunk s + 2 of the four term streams with coalesced 16-byte loads (a cell's terms are
+//               runs of 4^p consecutive x: whole cache lines per request instead of one line per lane and load, which
+//               held the first versions of this kernel at 3.8 and 1.9 ms per iteration), and put chunk s + 1, fetched
+//               during the previous stage, into the other LDS buffer;
+//   wave 0      (lanes 0..3 = a) adds chunk s from LDS, strictly in order: this IS the reference's rounding sequence.
+// A cell's chain is 4^(W-1) dependent float32 additions, about one per issue turn of its wave: what is left is that
+// chain (0.26 M additions at W = 10) plus one LDS read per four terms.  Cells and PWMs are independent: 10 x n_pwm
+// workgroups fill the chip from 26 PWMs on.
 template <int W>
-__global__ __launch_bounds__(128) void em_fold_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
+struct FoldGeo {
+  static constexpr uint32_t TERMS = 1u << (2 * W - 2);             // per cell
+  static constexpr uint32_t C = TERMS < 1024u ? TERMS : 1024u;     // terms per cell and stage
+  static constexpr uint32_t STAGES = TERMS / C;
+  static constexpr uint32_t QUADS = C;                             // 16-byte pieces per stage: 4 cells x C / 4
+  static constexpr uint32_t LOADERS = 128;
+  static constexpr uint32_t QPT = (QUADS + LOADERS - 1) / LOADERS;  // quads per loader thread and stage
+  static constexpr uint32_t ROW = C + 36;                          // floats per cell row in LDS: + 8 quads the adder may read past the
+                                                                   // end (never added), + 16 B (rows on different banks)
+};
+
+template <int W>
+__global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
                                                       double* __restrict__ partials) {
-  const int pw = blockIdx.x;
+  using F = FoldGeo<W>;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int pw = blockIdx.y;
   if (state[2 * pw + 1] == 0) return;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t p = blockIdx.x;  // position
   const uint32_t np = 1u << (2 * W);
-  const uint32_t n_terms = np / 4u;  // per cell
   const float* w = wbuf + (size_t)pw * np;
-  constexpr uint32_t DEPTH = (W >= 6) ? 4u : 1u;  // chunks of 16 terms per register buffer
-  static_assert(((1u << (2 * W - 2)) / 16u) % (2u * DEPTH) == 0u, "chunk count");
-  const uint32_t group = 16u * DEPTH;
-  float acc = 0.0f;
-  if (wave == 0) {
-    const uint32_t cell = lane + 4u;
-    if (cell >= (uint32_t)(W * 4)) return;
-    const uint32_t p = cell >> 2, a = cell & 3u;
-    const uint32_t run = 1u << (2 * p);  // the cell's terms come in runs of 4^p consecutive x, one run per 4^(p+1)
-    // term t is x(t) = ((t >> 2p) << (2p+2)) | (a << 2p) | (t & (run-1)); a chunk of 16 consecutive terms (t0 a
-    // multiple of 16) is four aligned quads: consecutive for runs >= 16, one quad per run for runs of 4 (p = 1)
-    const uint32_t quad_step = run >= 16u ? 4u : 16u;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    auto load_group = [&](uint32_t t0, f4 (&v)[DEPTH][4]) {
+  __shared__ __attribute__((aligned(16))) float buf[2][4][F::ROW];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t run = 1u << (2 * p);  // a cell's terms come in runs of 4^p consecutive x, one run per 4^(p+1)
+
+  // loader thread: quad q of a stage = terms 4 (q % (C/4)) .. + 3 of cell a = q / (C/4)
+  f4 pend[F::QPT];
+  const uint32_t lt = threadIdx.x - 64u;  // loader index (waves 1, 2)
+  auto fetch = [&](uint32_t stage) {
 #pragma unroll
-      for (uint32_t c = 0; c < DEPTH; ++c) {
-        const uint32_t t = t0 + 16u * c;
-        const uint32_t x0 = ((t >> (2 * p)) << (2 * p + 2)) | (a << (2 * p)) | (t & (run - 1u));
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) v[c][k] = *reinterpret_cast<const f4*>(w + x0 + k * quad_step);
-      }
-    };
-    auto add_group = [&](const f4 (&v)[DEPTH][4]) {  // strictly in order: this IS the reference's rounding sequence
-#pragma unroll
-      for (uint32_t c = 0; c < DEPTH; ++c)
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-          acc += v[c][k].x;
-          acc += v[c][k].y;
-          acc += v[c][k].z;
-          acc += v[c][k].w;
+    for (uint32_t i = 0; i < F::QPT; ++i) {
+      const uint32_t q = lt + i * F::LOADERS;
+      if (q < F::QUADS) {
+        if (p == 0) {  // position 0: term t of cell a is x = 4 t + a -- quad q holds term q of all four cells
+          pend[i] = *reinterpret_cast<const f4*>(w + 4u * (stage * F::C + q));
+        } else {
+          const uint32_t a = q / (F::C / 4u), t = stage * F::C + 4u * (q % (F::C / 4u));
+          const uint32_t x = ((t >> (2 * p)) << (2 * p + 2)) | (a << (2 * p)) | (t & (run - 1u));
+          pend[i] = *reinterpret_cast<const f4*>(w + x);
         }
-    };
-    f4 va[DEPTH][4], vb[DEPTH][4];
-    load_group(0, va);
-#pragma unroll 1
-    for (uint32_t t0 = 0; t0 < n_terms; t0 += 2u * group) {
-      load_group(t0 + group, vb);
-      add_group(va);
-      if (t0 + 2u * group < n_terms) load_group(t0 + 2u * group, va);
-      add_group(vb);
+      }
     }
-    partials[(size_t)pw * (W * 4) + cell] = (double)acc;  // layout of EmGeo<W, 16>: one "block" per PWM
-  } else {
-    if (lane >= 4u) return;
-    const uint32_t a = lane;  // position 0: term t is x = 4t + a
-    auto load_group = [&](uint32_t t0, float (&v)[DEPTH][16]) {
+  };
+  auto deposit = [&](uint32_t b) {
 #pragma unroll
-      for (uint32_t c = 0; c < DEPTH; ++c)
-#pragma unroll
-        for (uint32_t k = 0; k < 16; ++k) v[c][k] = w[4u * (t0 + 16u * c + k) + a];
-    };
-    auto add_group = [&](const float (&v)[DEPTH][16]) {
-#pragma unroll
-      for (uint32_t c = 0; c < DEPTH; ++c)
-#pragma unroll
-        for (uint32_t k = 0; k < 16; ++k) acc += v[c][k];
-    };
-    float va[DEPTH][16], vb[DEPTH][16];
-    load_group(0, va);
-#pragma unroll 1
-    for (uint32_t t0 = 0; t0 < n_terms; t0 += 2u * group) {
-      load_group(t0 + group, vb);
-      add_group(va);
-      if (t0 + 2u * group < n_terms) load_group(t0 + 2u * group, va);
-      add_group(vb);
+    for (uint32_t i = 0; i < F::QPT; ++i) {
+      const uint32_t q = lt + i * F::LOADERS;
+      if (q < F::QUADS) {
+        if (p == 0) {
+          buf[b][0][q] = pend[i].x;
+          buf[b][1][q] = pend[i].y;
+          buf[b][2][q] = pend[i].z;
+          buf[b][3][q] = pend[i].w;
+        } else {
+          const uint32_t a = q / (F::C / 4u), j = 4u * (q % (F::C / 4u));
+          *reinterpret_cast<f4*>(&buf[b][a][j]) = pend[i];
+        }
+      }
     }
-    partials[(size_t)pw * (W * 4) + a] = (double)acc;
+  };
+
+  if (wave != 0) {
+    fetch(0);
+    deposit(0);
+    if (F::STAGES > 1) fetch(1);
   }
+  __syncthreads();
+  float acc = 0.0f;
+#pragma unroll 1
+  for (uint32_t s = 0; s < F::STAGES; ++s) {
+    if (wave != 0) {
+      if (s + 1 < F::STAGES) deposit((s + 1) & 1u);  // fetched during the previous stage
+      if (s + 2 < F::STAGES) fetch(s + 2);
+    } else if (lane < 4u) {
+      // two register sets of 8 quads: the LDS reads of the next 32 terms are in flight while these 32 are added
+      const f4* src = reinterpret_cast<const f4*>(&buf[s & 1u][lane][0]);
+      constexpr uint32_t NQ = F::C / 4u, G = NQ < 8u ? NQ : 8u;
+      static_assert(NQ % (2u * G) == 0u || NQ == G, "quads per stage");
+      f4 va[G], vb[G];
+      auto rd = [&](f4 (&v)[G], uint32_t i0) {
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) v[k] = src[i0 + k];
+      };
+      auto add = [&](f4 (&v)[G]) {
+        // all quads of the set are "used" here at once: ONE s_waitcnt in front of the 4 G additions instead of one per
+        // quad (every instruction of the adding wave, waits included, costs the chain an issue turn)
+        if constexpr (G == 8)
+          asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) {
+          acc += v[k].x;
+          acc += v[k].y;
+          acc += v[k].z;
+          acc += v[k].w;
+        }
+      };
+      rd(va, 0);
+      if constexpr (NQ == G) {
+        add(va);
+      } else {
+#pragma unroll 1
+        for (uint32_t i = 0; i < NQ; i += 2u * G) {
+          // (scheduling barriers: left alone, the compiler moves each group of reads behind the additions in front
+          // of it and waits for every quad right after asking for it)
+          rd(vb, i + G);
+          __builtin_amdgcn_sched_barrier(0);
+          add(va);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(va, i + 2u * G);  // unconditional (a branch here costs 32 register moves per turn): the last turn reads
+          __builtin_amdgcn_sched_barrier(0);
+          add(vb);             // the row's padding and never adds it
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && lane < 4u) partials[(size_t)pw * (W * 4) + p * 4u + lane] = (double)acc;  // layout of EmGeo<W, 16>
 }
 
 // One block per PWM: sum the per-block partials in block order, then the reference's float32
@@ -489,8 +536,8 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
     for (int it = 0; it < max_it; ++it) {
       hipLaunchKernelGGL((em_weights_kernel<W>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
                          d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables);
-      hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)nb), dim3(128), 0, ctx->stream, d_state + 2 * first, ctx->d_em_tables,
-                         ctx->d_em_partials);
+      hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,
+                         ctx->d_em_tables, ctx->d_em_partials);
       hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
                          d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it);
     }
