@@ -143,7 +143,10 @@ int pengk_synth_sequences(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t
  * d_counts: uint32[4^W], overwritten.  both_strands: counts land on the canonical id min(id, rc)
  * only (run pengk_mirror_counts for the reference's twin copy, :387-392).  d_ltot: uint64 scalar,
  * overwritten with the number of visited windows.  The non-overlap rule (:361-366) is applied
- * exactly, with 64-bit positions.  Counts of different shards add (the rule is per sequence). */
+ * exactly, with 64-bit positions.  Counts of different shards add (the rule is per sequence).
+ * Emitters: W = 8, 10, 12 use the partitioned LDS-histogram count; W = 4, 6 (tables that are contended in any form)
+ * and W = 14 (2^28 bins = 2^13 LDS histograms: a third partition level that is not built -- the reference itself
+ * advises W <= 12, README.md:119) count with one device-scope atomic per window, about 20x slower per base. */
 int pengk_count(pengk_ctx* ctx, int both_strands, uint32_t* d_counts, uint64_t* d_ltot);
 int pengk_mirror_counts(pengk_ctx* ctx, int W, uint32_t* d_counts);
 /* pengk_count with K1b fused into the same scan (the rolling id's top three digits are the 3-mer ending at
@@ -210,6 +213,32 @@ int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturati
 int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold,
                     int max_iterations, const uint32_t* d_counts, const float* d_bg, int32_t* d_state,
                     float* d_change);
+
+/* ---- C1: the one exchange step of a multi-GPU run (no counterpart in the reference, which is a single
+ *      process).  One process per GPU; sequences shard by whole records; every rank counts its shard, then the
+ *      count table, ltot and the 84 background counters are summed over the ranks -- exact, because the non-overlap
+ *      rule never crosses a sequence boundary (src/base_pattern.cpp:382) -- by ONE grouped RCCL all-reduce over xGMI on
+ *      the context's stream.  Afterwards every rank holds the global tables: the sweeps are replicated, the EM splits
+ *      the PWM list, pengk_allgather returns the pieces.  librccl is opened on first use.
+ *
+ *      Rendezvous: either the caller distributes rank 0's id itself (pengk_comm_unique_id + pengk_comm_init, e.g. over
+ *      an existing launcher's store), or pengk_comm_init_env reads RANK / WORLD_SIZE / MASTER_ADDR from the launcher
+ *      environment (torchrun, mpirun wrappers) and hands the id out over TCP port PENGK_COMM_PORT (default
+ *      MASTER_PORT + 17).  With WORLD_SIZE unset or 1 every call below is a no-op that succeeds. */
+#define PENGK_COMM_ID_BYTES 128
+int pengk_comm_unique_id(void* id_out /* PENGK_COMM_ID_BYTES */);
+int pengk_comm_init(pengk_ctx* ctx, const void* id, int rank, int world);
+int pengk_comm_init_env(pengk_ctx* ctx);
+int pengk_comm_info(pengk_ctx* ctx, int* rank_out, int* world_out);
+int pengk_comm_destroy(pengk_ctx* ctx);
+/* In-place sum over the ranks of d_counts uint32[4^W] (the global bin bound must stay below 2^32: the caller checks
+ * the sum of its shards' pengk_packed.max_bin_bound), d_ltot uint64[1] and, if not NULL, d_bg uint64[84]. */
+int pengk_allreduce_tables(pengk_ctx* ctx, int W, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg_counts);
+/* Sums the attached shards' bin bounds (pengk_set_sequences' max_bin_bound) over the ranks and fails with
+ * PENGK_ERR_RANGE when a 32-bit bin could overflow globally.  Collective; synchronises with the host. */
+int pengk_comm_check_bin_bound(pengk_ctx* ctx);
+/* d_recv[r * bytes_per_rank ...) = rank r's d_send[0 .. bytes_per_rank), for every r (ncclAllGather). */
+int pengk_allgather(pengk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -27,6 +27,8 @@ EXPORTS = [
     "pengk_pack", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
     "pengk_count", "pengk_count_bg", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
     "pengk_iupac_aggregate", "pengk_em", "pengk_em_device",
+    "pengk_comm_unique_id", "pengk_comm_init", "pengk_comm_init_env", "pengk_comm_info", "pengk_comm_destroy",
+    "pengk_allreduce_tables", "pengk_comm_check_bin_bound", "pengk_allgather",
 ]
 
 
@@ -93,6 +95,14 @@ def lib():
         L.pengk_iupac_aggregate.argtypes = [vp, C.c_int, C.c_int, vp, i64, vp, vp, vp, vp]
         L.pengk_em.argtypes = [vp, C.c_int, i64, vp, f32, f32, C.c_int, vp, vp, vp, vp]
         L.pengk_em_device.argtypes = [vp, C.c_int, i64, vp, f32, f32, C.c_int, vp, vp, vp, vp]
+        L.pengk_comm_unique_id.argtypes = [vp]
+        L.pengk_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.pengk_comm_init_env.argtypes = [vp]
+        L.pengk_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.pengk_comm_destroy.argtypes = [vp]
+        L.pengk_allreduce_tables.argtypes = [vp, C.c_int, vp, vp, vp]
+        L.pengk_comm_check_bin_bound.argtypes = [vp]
+        L.pengk_allgather.argtypes = [vp, vp, vp, C.c_size_t]
         _lib = L
     return _lib
 

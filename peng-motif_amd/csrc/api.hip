@@ -106,6 +106,7 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (!ctx) return PENGK_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  comm_release(ctx);
   if (ctx->d_defer) (void)hipFree(ctx->d_defer);
   if (ctx->d_em_partials) (void)hipFree(ctx->d_em_partials);
   if (ctx->d_em_tables) (void)hipFree(ctx->d_em_tables);

@@ -238,13 +238,31 @@ void fast_items(const int64_t* offs, int64_t s0, int64_t s1, int W, uint64_t M, 
   }
 }
 
+// Threads that are always joined: if starting one throws (std::system_error) while others run, unwinding would
+// destroy joinable std::thread objects -- std::terminate before any catch.  The destructor joins what was started.
+struct ThreadGroup {
+  std::vector<std::thread> th;
+  template <class... A>
+  void spawn(A&&... a) { th.emplace_back(std::forward<A>(a)...); }
+  void join() {
+    for (auto& x : th)
+      if (x.joinable()) x.join();
+  }
+  ~ThreadGroup() { join(); }
+};
+
 template <class F>
 void run_ranges(unsigned nt, F&& f) {
-  std::vector<std::thread> th;
-  for (unsigned t = 1; t < nt; ++t) th.emplace_back(f, t);
+  ThreadGroup g;
+  for (unsigned t = 1; t < nt; ++t) g.spawn(f, t);
   f(0u);
-  for (auto& x : th) x.join();
+  g.join();
 }
+
+struct FreeGuard {  // malloc'ed scratch released on every exit path unless handed over
+  void* p;
+  ~FreeGuard() { free(p); }
+};
 
 // the whole fast path; returns 0 when the input needs the general path (out untouched except for scratch it frees)
 int pack_fast(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, int item_windows, unsigned nt,
@@ -254,6 +272,7 @@ int pack_fast(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, i
   const uint64_t n_words = (PENGK_FRONT_PAD_BASES + total + 31) / 32 + 4;
   uint64_t* words = (uint64_t*)calloc(n_words, sizeof(uint64_t));
   if (!words) return 0;
+  FreeGuard words_guard{words};  // a failing thread start below must not leak the stream
   std::vector<FastStat> st(nt);
   run_ranges(nt, [&](unsigned t) {
     fast_range(codes, offs, cut[t], cut[t + 1], W, M, PENGK_FRONT_PAD_BASES + (uint64_t)(offs[cut[t]] - offs[0]), words, st[t]);
@@ -262,10 +281,7 @@ int pack_fast(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, i
   std::vector<uint64_t> item0(nt);
   uint64_t h3[64] = {0}, e1[16] = {0}, e0[4] = {0};
   for (unsigned t = 0; t < nt; ++t) {
-    if (!st[t].ok) {
-      free(words);
-      return 0;
-    }
+    if (!st[t].ok) return 0;  // (the guard frees the stream)
     item0[t] = n_items;
     n_windows += st[t].windows;
     n_items += st[t].items;
@@ -276,10 +292,8 @@ int pack_fast(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, i
     for (int i = 0; i < 4; ++i) e0[i] += st[t].e0[i];
   }
   uint64_t* items = (uint64_t*)malloc((n_items ? n_items : 1) * sizeof(uint64_t));
-  if (!items) {
-    free(words);
-    return 0;
-  }
+  if (!items) return 0;
+  FreeGuard items_guard{items};
   run_ranges(nt, [&](unsigned t) { fast_items(offs, cut[t], cut[t + 1], W, M, item0[t], items); });
 
   // background counters (BaMM index: first base in the HIGH digit) from the 3-mer histogram and the head k-mers
@@ -297,6 +311,8 @@ int pack_fast(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, i
 
   out->words = words;
   out->items = items;
+  words_guard.p = nullptr;  // handed over
+  items_guard.p = nullptr;
   out->n_words = n_words;
   out->n_items = n_items;
   out->n_bases = total;
@@ -353,11 +369,10 @@ extern "C" int pengk_pack(const uint8_t* codes, const int64_t* offs, int64_t n_s
   memset(out, 0, sizeof *out);
   std::vector<RangeStat> st(nt);
   try {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; ++t)
-      th.emplace_back(measure_range, codes, offs, cut[t], cut[t + 1], W, M, std::ref(st[t]));
+    ThreadGroup g;
+    for (unsigned t = 1; t < nt; ++t) g.spawn(measure_range, codes, offs, cut[t], cut[t + 1], W, M, std::ref(st[t]));
     measure_range(codes, offs, cut[0], cut[1], W, M, st[0]);
-    for (auto& x : th) x.join();
+    g.join();
   } catch (const std::exception&) {
     return fail(PENGK_ERR_NOMEM, "pengk_pack: cannot start host threads");
   }
@@ -387,12 +402,17 @@ extern "C" int pengk_pack(const uint8_t* codes, const int64_t* offs, int64_t n_s
     memset(out, 0, sizeof *out);
     return fail(PENGK_ERR_NOMEM, "pengk_pack: out of host memory");
   }
-  {
-    std::vector<std::thread> th;
+  try {
+    ThreadGroup g;
     for (unsigned t = 1; t < nt; ++t)
-      th.emplace_back(write_range, codes, offs, cut[t], cut[t + 1], W, M, base0[t], item0[t], out->words, out->items);
+      g.spawn(write_range, codes, offs, cut[t], cut[t + 1], W, M, base0[t], item0[t], out->words, out->items);
     write_range(codes, offs, cut[0], cut[1], W, M, base0[0], item0[0], out->words, out->items);
-    for (auto& x : th) x.join();
+    g.join();
+  } catch (const std::exception&) {
+    free(out->words);
+    free(out->items);
+    memset(out, 0, sizeof *out);
+    return fail(PENGK_ERR_NOMEM, "pengk_pack: cannot start host threads");
   }
   out->n_words = n_words;
   out->n_items = n_items;

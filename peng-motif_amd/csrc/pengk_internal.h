@@ -42,6 +42,8 @@ struct pengk_ctx {
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms
   int scatter_blocks_per_cu = 0; // tuning hook: workgroups per CU of the partitioned scan (0 = default)
+  void* comm = nullptr;          // RCCL communicator (comm.hip); NULL = single rank
+  int comm_rank = 0, comm_world = 1;
 };
 
 namespace pengk {
@@ -51,6 +53,7 @@ int hip_fail(hipError_t e, const char* what);
 int ensure_scratch(pengk_ctx* ctx, void** slot, size_t* have, size_t need);
 int enter(pengk_ctx* ctx);      // hipSetDevice(ctx->device)
 int count_init_device();        // per-device kernel attributes of count.hip (current device)
+void comm_release(pengk_ctx* ctx);  // destroys the RCCL communicator, if any
 
 #define PENGK_HIP(call)                                   \
   do {                                                    \

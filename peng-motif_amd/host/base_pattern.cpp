@@ -30,8 +30,12 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
 
   // ---- sequences -> 2-bit stream + scan items (host packer resolves the N / skip scan rule) ----------
   pengk_host::Lap lap("    ");
+  // multi-GPU run: this rank scans its contiguous shard of whole records; the tables are summed below
+  size_t s_lo = 0, s_hi = sequence_set->getN();
+  const int n_ranks = pengk_host::world();
+  if (n_ranks > 1) pengk_host::shard_range(sequence_set->getN(), pengk_host::rank(), n_ranks, &s_lo, &s_hi);
   pengk_packed pk;
-  check(pengk_pack(sequence_set->codes(), sequence_set->offsets(), (int64_t)sequence_set->getN(), W, 0, &pk), "pengk_pack");
+  check(pengk_pack(sequence_set->codes(), sequence_set->offsets() + s_lo, (int64_t)(s_hi - s_lo), W, 0, &pk), "pengk_pack");
   lap("pack");
   pengk_host::DeviceBuffer<uint64_t> d_words(pk.n_words), d_items(pk.n_items + 1), d_ltot(1);
   d_words.upload(pk.words, pk.n_words);
@@ -46,6 +50,12 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
   // ---- K1 count (+ twin copy), K2+K3 sweep ---------------------------------------------------------------
   d_counts.resize(NP);
   check(pengk_count(context(), both, d_counts.get(), d_ltot.get()), "pengk_count");
+  if (n_ranks > 1) {
+    // C1, the one exchange step: shard counts add exactly (the non-overlap rule is per sequence, src/base_pattern.cpp:382).
+    // The 32-bit bins must hold the GLOBAL counts: the bound is all-reduced and checked first.
+    check(pengk_comm_check_bin_bound(context()), "pengk_comm_check_bin_bound");
+    check(pengk_allreduce_tables(context(), W, d_counts.get(), d_ltot.get(), nullptr), "pengk_allreduce_tables");
+  }
   if (both) check(pengk_mirror_counts(context(), W, d_counts.get()), "pengk_mirror_counts");
 
   float hV[84] = {0};

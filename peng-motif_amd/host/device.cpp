@@ -1,5 +1,6 @@
 #include "device.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -10,6 +11,26 @@
 namespace pengk_host {
 
 static pengk_ctx* g_ctx = nullptr;
+
+static int env_int(const char* name, int fallback) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : fallback;
+}
+int world() {
+  static const int w = std::max(1, env_int("WORLD_SIZE", 1));
+  return w;
+}
+int rank() {
+  static const int r = world() > 1 ? env_int("RANK", 0) : 0;
+  return r;
+}
+static int device_index() { return world() > 1 ? env_int("LOCAL_RANK", rank()) : Global::device; }
+
+void shard_range(size_t n, int r, int w, size_t* lo, size_t* hi) {
+  const size_t base = n / (size_t)w, rem = n % (size_t)w;
+  *lo = (size_t)r * base + std::min<size_t>((size_t)r, rem);
+  *hi = *lo + base + ((size_t)r < rem ? 1 : 0);
+}
 
 void check(int rc, const char* what) {
   if (rc == PENGK_OK) return;
@@ -29,7 +50,7 @@ static void join_starter() {
 void start_context() {
   if (g_ctx || g_starter.joinable()) return;
   g_starter = std::thread([] {
-    g_starter_rc = pengk_create(Global::device, &g_ctx);
+    g_starter_rc = pengk_create(device_index(), &g_ctx);
     if (g_starter_rc != PENGK_OK) g_starter_error = pengk_last_error();  // the message is thread local
   });
   atexit(join_starter);  // an exit() on a FASTA error must not tear the process down under a starting runtime
@@ -43,7 +64,7 @@ pengk_ctx* context() {
       exit(1);
     }
   }
-  if (!g_ctx) check(pengk_create(Global::device, &g_ctx), "pengk_create");
+  if (!g_ctx) check(pengk_create(device_index(), &g_ctx), "pengk_create");
   static bool options_set = false;
   if (!options_set) {
     options_set = true;
@@ -54,6 +75,7 @@ pengk_ctx* context() {
     int mode = 2;
     if (const char* e = std::getenv("PENGK_EM_FAST")) mode = std::atoi(e);
     check(pengk_set_option(g_ctx, "em_fast", mode), "pengk_set_option");
+    if (world() > 1) check(pengk_comm_init_env(g_ctx), "pengk_comm_init_env");  // RCCL over xGMI; collective: every rank gets here
   }
   return g_ctx;
 }

@@ -19,6 +19,14 @@ void start_context();           // optional: begin creating it on a helper threa
 void shutdown();
 void check(int rc, const char* what);
 
+// Multi-GPU runs: one process per GPU, started by a launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (torchrun,
+// mpirun wrappers).  Read from the environment BEFORE any GPU call; the context then lives on device LOCAL_RANK and
+// carries an RCCL communicator (pengk_comm_init_env).  Without a launcher: rank 0 of 1.
+int rank();
+int world();
+// contiguous whole-record shard [lo, hi) of rank r: sizes differ by at most one
+void shard_range(size_t n, int r, int w, size_t* lo, size_t* hi);
+
 // PENGK_TIMING=1: wall-clock report of sub-phases on stderr (stdout stays the reference's trace)
 struct Lap {
   using clk = std::chrono::steady_clock;

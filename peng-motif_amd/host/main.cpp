@@ -2,6 +2,7 @@
 // and exit codes as the reference's src/main.cpp; the hot loops run on the GPU through libpengk.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <iostream>
 
@@ -30,6 +31,9 @@ struct PhaseClock {
 
 int main(int nargs, char** args) {
   PhaseClock clock;
+  // multi-GPU run (one process per GPU under a launcher): every rank reads the input and follows the same
+  // deterministic control flow on the all-reduced tables; rank 0 alone reports and writes
+  if (pengk_host::rank() != 0 && !std::freopen("/dev/null", "w", stdout)) return 1;
   Global::init(nargs, args);
   clock.lap("read FASTA");
   pengk_host::context();  // fail early (exit 1) when no gfx950 device is present: there is no CPU path
@@ -65,8 +69,10 @@ int main(int nargs, char** args) {
   peng.process(params, result);
   clock.lap("process (count, sweep, hill-climb, PWMs, EM, merging)");
   peng.filter_redundancy(Global::mergeBitfactorThreshold, result);
-  if (Global::outputFilename) peng.printShortMeme(result, Global::outputFilename, bgModel);
-  if (Global::jsonFilename) peng.printJson(result, Global::jsonFilename, VERSION_NUMBER, bgModel);
+  if (pengk_host::rank() == 0) {
+    if (Global::outputFilename) peng.printShortMeme(result, Global::outputFilename, bgModel);
+    if (Global::jsonFilename) peng.printJson(result, Global::jsonFilename, VERSION_NUMBER, bgModel);
+  }
 
   for (IUPACPattern* p : result) delete p;
   delete bgModel;

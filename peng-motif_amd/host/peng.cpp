@@ -65,11 +65,34 @@ void Peng::em_optimize_pwms(std::vector<IUPACPattern*>& patterns, BasePattern* b
   for (size_t i = 0; i < n; ++i)
     for (size_t p = 0; p < W; ++p)
       for (int a = 0; a < 4; ++a) pw[(i * W + p) * 4 + a] = patterns[i]->get_pwm()[p][a];
-  if (n)
+  const int n_ranks = pengk_host::world(), me = pengk_host::rank();
+  if (n && n_ranks == 1) {
     pengk_host::check(pengk_em(pengk_host::context(), (int)W, (int64_t)n, pw.data(), saturation_factor, min_em_threshold,
                                max_iterations, base_patterns->device_counts(), base_patterns->device_bgprob(background_order),
                                nullptr, nullptr),
                       "pengk_em");
+  } else if (n) {
+    // multi-GPU: PWM i belongs to rank i mod n_ranks (PWMs are independent); an all-gather of equal blocks returns
+    // every rank's results to every rank -- block r holds PWMs r, r + n_ranks, ... in that order, zero padded
+    const size_t cell = W * 4, per = (n + (size_t)n_ranks - 1) / (size_t)n_ranks;
+    std::vector<float> mine(per * cell, 0.0f), all((size_t)n_ranks * per * cell);
+    size_t n_mine = 0;
+    for (size_t i = (size_t)me; i < n; i += (size_t)n_ranks, ++n_mine)
+      std::copy(pw.begin() + i * cell, pw.begin() + (i + 1) * cell, mine.begin() + n_mine * cell);
+    if (n_mine)
+      pengk_host::check(pengk_em(pengk_host::context(), (int)W, (int64_t)n_mine, mine.data(), saturation_factor, min_em_threshold,
+                                 max_iterations, base_patterns->device_counts(),
+                                 base_patterns->device_bgprob(background_order), nullptr, nullptr),
+                        "pengk_em");
+    pengk_host::DeviceBuffer<float> d_mine(per * cell), d_all((size_t)n_ranks * per * cell);
+    d_mine.upload(mine.data(), per * cell);
+    pengk_host::check(pengk_allgather(pengk_host::context(), d_mine.get(), d_all.get(), per * cell * sizeof(float)), "pengk_allgather");
+    d_all.download(all.data(), all.size());
+    for (size_t i = 0; i < n; ++i) {
+      const size_t r = i % (size_t)n_ranks, k = i / (size_t)n_ranks;
+      std::copy(all.begin() + (r * per + k) * cell, all.begin() + (r * per + k + 1) * cell, pw.begin() + i * cell);
+    }
+  }
   for (size_t i = 0; i < n; ++i) {
     std::vector<float*> rows(W);
     for (size_t p = 0; p < W; ++p) rows[p] = &pw[(i * W + p) * 4];

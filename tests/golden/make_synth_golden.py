@@ -24,6 +24,12 @@ CASES = [  # seed, seq0, n_seq, L, W, strand
     (1, 0, 60_000, 200, 12, "BOTH"),
     (3, 777, 40_000, 150, 12, "PLUS"),
     (2, 10, 30_000, 90, 8, "BOTH"),
+    # BASELINE configs[3] (100M x 200 bp, W = 12, 8 shards): the head of shard 0 at the largest size the compiled
+    # reference handles comfortably here (400 Mbp; its positions are 32-bit and its tables 8-byte)
+    (1, 0, 2_000_000, 200, 12, "BOTH"),
+    # ... and one WHOLE shard of it (shard 3 of 8: sequences [37.5M, 50M)): 2.65e9 positions, just inside the
+    # reference's 32-bit position counters; about 30 GB of host memory and ten minutes
+    (1, 37_500_000, 12_500_000, 200, 12, "BOTH"),
 ]
 
 
@@ -32,15 +38,21 @@ def sha(a):
 
 
 def main():
-    out = []
+    path = os.path.join(HERE, "synth_checksums.json")
+    out = json.load(open(path)) if os.path.exists(path) and "--all" not in sys.argv else []
+    have = {(r["seed"], r["seq0"], r["n_seq"], r["L"], r["W"], r["strand"]) for r in out}
     for seed, seq0, n, L, W, strand in CASES:
+        if (seed, seq0, n, L, W, strand) in have:
+            continue
         codes, offs = po.synth(seed, seq0, n, L)
         tmp = tempfile.mkdtemp(prefix="synthref_")
         fa = os.path.join(tmp, "s.fa")
         lut = np.frombuffer(b"NACGT", dtype=np.uint8)
         rows = lut[codes].reshape(n, L)
         with open(fa, "wb") as f:
-            f.write(b"".join((">s%d\n" % (seq0 + i)).encode() + rows[i].tobytes() + b"\n" for i in range(n)))
+            for lo in range(0, n, 250_000):  # in pieces: the whole-shard case is a 2.7 GB file
+                f.write(b"".join((">s%d\n" % (seq0 + i)).encode() + rows[i].tobytes() + b"\n" for i in range(lo, min(n, lo + 250_000))))
+        del rows
         subprocess.check_call([REF_DUMP, fa, str(W), strand, tmp, "tables"], stderr=subprocess.DEVNULL)
         ld = lambda f_, t: np.fromfile(os.path.join(tmp, f_), t)  # noqa: E731
         meta = dict(l.split() for l in open(os.path.join(tmp, "meta.txt")))
@@ -54,8 +66,10 @@ def main():
         oc, lt = po.count(codes, offs, W, strand == "BOTH")
         assert lt == rec["ltot"] and sha(oc.astype(np.uint32)) == rec["sha_counts_u32"], "oracle != reference"
         out.append(rec)
-        print(W, strand, n, "ltot", rec["ltot"], "seeds", len(rec["seeds"]))
-    json.dump(out, open(os.path.join(HERE, "synth_checksums.json"), "w"), indent=1)
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+        print(W, strand, n, "ltot", rec["ltot"], "seeds", len(rec["seeds"]), flush=True)
+    json.dump(out, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":

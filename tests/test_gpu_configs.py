@@ -1,0 +1,128 @@
+"""BASELINE.json configs[3] and configs[4] at their real sizes, through the C ABI.
+
+configs[3]  "Synthetic 100M x 200 bp, W=12, seqs sharded 8 x MI355X": ONE shard of 12.5M sequences on the one GPU of
+            the test box (the reference cannot run it: 2.5e9 positions wrap its 32-bit counters), checked
+            through size-independent properties -- ltot, shard additivity (what the all-reduce relies on), the two
+            independent emitters (direct atomics vs two-level partition) bin for bin, fused background totals -- and,
+            at the largest size the compiled reference handles in the build container (2M sequences = 400 Mbp, the
+            head of shard 0), against sha256 checksums of the reference's own tables (tests/golden/synth_checksums.json,
+            exercised by test_gpu_parity.py::test_device_generated_input_against_reference_checksums).
+configs[4]  "W=10 --strand PLUS, 1000 seed PWMs, EM-only stress" exactly as SURVEY.md 8(d) defines it: the PLUS count
+            table of the 10M x 200 bp set, the 1000 highest-count k-mers (ties by ascending id) as seeds, initial PWM
+            row 0.7 at the seed's base and 0.1 elsewhere, --em-threshold 0, 10 iterations = 1.05e10 evaluations.
+            Sampled PWMs against the oracle: the library's default mode within BASELINE.json's 1e-5 relative of the
+            fp64-accumulating restatement, the serial mode (what the CLI runs) bit for bit.
+"""
+import numpy as np
+import pytest
+
+import peng_motif_amd as pk
+from oracle import oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pk.Context(0)
+    yield c
+    c.close()
+
+
+def _count(ctx, seq0, n, L, W, both, impl=0, bg=False):
+    ctx.synth(1, seq0, n, L, W)
+    ctx.set_option("count_impl", impl)
+    try:
+        if bg:
+            c, lt, b = ctx.count_bg(both)
+            return c.to_host(), int(lt.to_host()[0]), b.to_host()
+        c, lt = ctx.count(both)
+        return c.to_host(), int(lt.to_host()[0])
+    finally:
+        ctx.set_option("count_impl", 0)
+
+
+def test_config3_one_w12_shard_of_12_5M_sequences(ctx):
+    W, L, n = 12, 200, 12_500_000
+    shard = 3  # sequences [37.5M, 50M) of the 100M-sequence set
+    seq0 = shard * n
+    whole, lt, bg = _count(ctx, seq0, n, L, W, True, bg=True)
+    assert lt == n * (L - W + 1)
+    # fused background counters: totals follow from the geometry; the 1- and 2-mer marginals from the 3-mers
+    assert int(bg[:4].sum()) == n * L and int(bg[4:20].sum()) == n * (L - 1) and int(bg[20:].sum()) == n * (L - 2)
+    # shard additivity, bit for bit (the non-overlap rule never crosses a sequence boundary)
+    a, la = _count(ctx, seq0, n // 2, L, W, True)
+    acc = a.astype(np.uint64)
+    del a
+    b, lb = _count(ctx, seq0 + n // 2, n - n // 2, L, W, True)
+    assert la + lb == lt
+    acc += b
+    del b
+    assert np.array_equal(acc, whole.astype(np.uint64))
+    del acc
+    # counted + suppressed == visited, suppressed fraction tiny on random DNA (7.5e-6 at W = 10)
+    counted = int(whole.astype(np.uint64).sum())
+    assert 0 <= lt - counted < 1e-4 * lt
+    # the direct-atomic emitter is an independent implementation of the same scan: every bin must agree
+    direct, ld = _count(ctx, seq0, n, L, W, True, impl=1)
+    assert ld == lt and np.array_equal(direct, whole)
+    # plus strand at the same size: the emitters agree there too
+    p2, lp = _count(ctx, seq0, n, L, W, False, impl=2)
+    d2, _ = _count(ctx, seq0, n, L, W, False, impl=1)
+    assert lp == lt and np.array_equal(p2, d2)
+    assert int(p2.astype(np.uint64).sum()) >= counted  # the revcomp twin can only suppress more
+
+
+def _top_seeds(counts, n):
+    """the n highest-count k-mers, ties by ascending id"""
+    order = np.lexsort((np.arange(counts.size), -counts.astype(np.int64)))[:n]
+    return order
+
+
+def _seed_pwms(seeds, W):
+    pw = np.full((len(seeds), W, 4), 0.1, np.float32)
+    for i, x in enumerate(seeds):
+        for q in range(W):
+            pw[i, q, (int(x) >> (2 * q)) & 3] = 0.7
+    return pw
+
+
+def test_config4_em_stress_1000_top_count_seeds_plus_table(ctx):
+    W, L, n, K = 10, 200, 10_000_000, 2
+    ctx.synth(1, 0, n, L, W)
+    counts, ltot, bg = ctx.count_bg(False)  # PLUS: no mirror, no strand aggregation
+    V = ctx.bg_model(bg, K)
+    bgprob, expected, logp, z = ctx.pattern_stats(W, False, K, K, V, ltot, counts)
+    c_host = counts.to_host()
+    assert int(ltot.to_host()[0]) == n * (L - W + 1)
+    seeds = _top_seeds(c_host, 1000)
+    assert po.kmer_str(int(seeds[0]), W) == "GCTGAGTCAT"  # the planted motif has by far the highest plus-strand count
+    pw0 = _seed_pwms(seeds, W)
+    bgk_host = bgprob.to_host()[K]
+    bg_k = pk.DeviceArray.from_host(ctx, bgk_host)
+    sample = [0, 1, 2, 17, 255, 256, 500, 777, 998, 999]
+    c64 = c_host.astype(np.uint64)
+
+    # library default (em_fast = 1): 1e-5 relative against the fp64-accumulating oracle, iteration counts equal
+    got, iters, change = ctx.em(W, pw0, counts, bg_k, 1e4, 0.0, 10)
+    assert (iters == 10).all()
+    assert np.allclose(got.sum(axis=2), 1.0, atol=1e-6)
+    for i in sample:
+        ref, it, _ = po.em(W, c64, bgk_host, pw0[i], 1e4, 0.0, 10, mode=1, final_norm=False)
+        assert it == 10
+        rel = np.abs(got[i].astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-3)
+        assert rel.max() <= 1e-5, (i, rel.max())
+
+    # serial mode (the CLI's): the reference's float32 sums in the reference's order, bit for bit
+    ctx.set_option("em_fast", 2)
+    try:
+        ser, it2, ch2 = ctx.em(W, pw0, counts, bg_k, 1e4, 0.0, 10)
+    finally:
+        ctx.set_option("em_fast", 1)
+    assert (it2 == 10).all()
+    for i in sample:
+        ref, it, ch = po.em(W, c64, bgk_host, pw0[i], 1e4, 0.0, 10, mode=0, final_norm=False)
+        assert ser[i].tobytes() == ref.astype(np.float32).tobytes(), i
+        assert np.float32(ch2[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
+    # the two modes agree within the reference's own float32 envelope (up to 2.6e-4 relative)
+    assert np.abs(ser.astype(np.float64) - got).max() <= 1e-4
