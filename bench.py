@@ -7,21 +7,28 @@ timed region), W=10, both strands, background order 2.  One "step" = one full pa
 over that batch:
 
     K1  4^W k-mer count with K1b (background 3-mers) fused  pengk_count_bg
-    C1  all-reduce(sum) of {counts, ltot, bg counts}        torch.distributed (RCCL), N > 1 only
+    C1  all-reduce(sum) of {counts, ltot, bg counts}        pengk_allreduce_tables (RCCL over xGMI, N > 1 only)
         mirror, background model V                          pengk_mirror_counts / pengk_bg_model
     K2+K3 sweep over 4^W patterns (bgprob, expected, log-p, z)   pengk_pattern_stats
     K5  EM: P seed PWMs x 10 iterations over the 4^W table   pengk_em_device (PWMs split over ranks)
+
+The EM inside the step runs in the mode the peng_motif CLI ships with (em_fast = 2: the reference's float32 sums in the
+reference's order, bit-exact); the library's throughput mode (em_fast = 1, within BASELINE.json's 1e-5) is timed on the
+same batch and reported beside it.
 
 Weak scaling: every rank holds its own 10M-sequence shard (sequences [rank*n, (rank+1)*n) of one
 global synthetic set).  `value` is whole-job Gbp/s = bases of all ranks / step time; the component
 rates of BASELINE.json's metric (z-scores/s, EM evals/s, count Gbp/s) are reported beside it from
 HIP-event timings taken inside the timed steps on the stream the kernels run on.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  Started without a launcher
+and N > 1 it starts `python -m torch.distributed.run` itself (before anything touches the GPU) and relays the line.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,10 +37,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+FP32_VECTOR_PEAK_TF = 157.3  # dense fp32 vector peak (same guide); K5 has no contraction for the matrix cores
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -46,13 +54,39 @@ def main():
     ap.add_argument("--em-iters", type=int, default=10)
     ap.add_argument("--k4-patterns", type=int, default=2000,
                     help="K4 probe after the timed steps: degenerate IUPAC patterns of one hill-climb round (0 = off)")
-    ap.add_argument("--em-fast", type=int, default=1, help="pengk option em_fast (one reciprocal per k-mer weight)")
+    ap.add_argument("--em-fast", type=int, default=2,
+                    help="pengk option em_fast inside the step: 2 = serial bit-exact (the CLI's mode), 1 = one reciprocal per weight, 0 = reference terms")
     ap.add_argument("--em-stress-pwms", type=int, default=1000,
-                    help="BASELINE configs[4]: EM-only stress on this many seed PWMs (split over ranks), timed after the steps; 0 = skip")
+                    help="BASELINE configs[4]: EM-only stress on this many top-count seeds of the PLUS table (split over ranks); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end peng_motif CLI run on the config's FASTA")
     ap.add_argument("--count-impl", type=int, default=0, help="0 auto, 1 direct atomics, 2 partitioned")
     ap.add_argument("--cpu-sample-seqs", type=int, default=6_000_000)
-    args = ap.parse_args()
+    ap.add_argument("--checks", action="store_true", help="add sha256 checksums of the reduced tables and the EM result to the line")
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as a CHILD process (this process has not
+    touched the GPU and never execs) and relay its output."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
 
     import torch
     import peng_motif_amd as pk
@@ -61,12 +95,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s); start it as `python bench.py --gpus N` or with "
+                 "--nproc-per-node equal to --gpus" % (args.gpus, world))
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # PENGK_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
-        # (ranks share devices, collectives go through the host).  The measured runs use nccl (= RCCL).
+        # (ranks share devices, the exchange goes through the host).  The measured runs use RCCL.
         backend = os.environ.get("PENGK_BENCH_BACKEND", "nccl")
         if backend != "nccl":
             local_rank = local_rank % torch.cuda.device_count()
@@ -78,8 +116,6 @@ def main():
     else:
         torch.cuda.set_device(0)
         local_rank = 0
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d != WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank)
 
     W, both, L, nseq = args.W, args.strand == "BOTH", args.L, args.nseq
@@ -88,20 +124,39 @@ def main():
     ctx = pk.Context(local_rank)
     ctx_stream = torch.cuda.Stream(device=dev)
     lib = pk.lib()
-    pk._check(lib.pengk_set_stream(ctx.h, ctx_stream.cuda_stream))  # kernels + collectives share one stream
+    pk._check(lib.pengk_set_stream(ctx.h, ctx_stream.cuda_stream))  # kernels + the exchange share one stream
     ctx.set_option("count_impl", args.count_impl)
     ctx.set_option("em_fast", args.em_fast)
 
+    import ctypes as C
+    rccl_ranks = 1
+    if world > 1 and backend == "nccl":
+        # the exchange step runs in the C++ library (RCCL on the context's stream); torch.distributed only carries the
+        # 128-byte communicator id to the ranks, the barriers around the timed region and the max over ranks
+        box = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            pk._check(lib.pengk_comm_unique_id(buf))
+            box[0] = buf.raw
+        dist.broadcast_object_list(box, src=0)
+        pk._check(lib.pengk_comm_init(ctx.h, box[0], rank, world))
+        r_, w_ = C.c_int(), C.c_int()
+        pk._check(lib.pengk_comm_info(ctx.h, C.byref(r_), C.byref(w_)))
+        rccl_ranks = w_.value
+        assert (r_.value, w_.value) == (rank, world)
+
     with torch.cuda.stream(ctx_stream):
         # ---- resident input: this rank's shard of the global synthetic set -------------------------
-        import ctypes as C
         nw, ni = C.c_uint64(), C.c_uint64()
         pk._check(lib.pengk_synth_sizes(nseq, L, W, 0, C.byref(nw), C.byref(ni)))
         words = torch.empty(nw.value, dtype=torch.int64, device=dev)
         items = torch.empty(max(ni.value, 1), dtype=torch.int64, device=dev)
         ctx.synth(1, rank * nseq, nseq, L, W, 0, words, items)
         nwin = L - W + 1
-        sharding.check_global_bin_bound(nseq * ((nwin + W - 1) // W), dist)
+        if rccl_ranks > 1:
+            pk._check(lib.pengk_comm_check_bin_bound(ctx.h))
+        else:
+            sharding.check_global_bin_bound(nseq * ((nwin + W - 1) // W), dist)
         counts = torch.empty(NP, dtype=torch.int32, device=dev)           # uint32 bins (bit pattern)
         scal = torch.zeros(85, dtype=torch.int64, device=dev)             # [0:84] bg counts, [84] ltot
         V = torch.empty(84, dtype=torch.float32, device=dev)
@@ -109,18 +164,22 @@ def main():
         expected = torch.empty(NP, dtype=torch.float32, device=dev)
         logp = torch.empty(NP, dtype=torch.float32, device=dev)
         z = torch.empty(NP, dtype=torch.float32, device=dev)
-        # EM seeds: P PWMs for the whole job, split over ranks; seed k-mers are fixed ids (results are
-        # not inspected here -- parity is the tests' job -- only the arithmetic volume matters)
+        # EM seeds of the step: P PWMs for the whole job, split over ranks; fixed pseudo-random seed k-mers (the EM
+        # stress below uses the seeds SURVEY.md 8d specifies; parity of both is the tests' job)
         P_total = args.pwms
         my_pwms = [i for i in range(P_total) if i % world == rank]
         n_my = len(my_pwms)
         rng = np.random.default_rng(5)
         seed_ids = rng.integers(0, NP, size=P_total)
-        pw0 = np.full((max(n_my, 1), W, 4), 0.1, np.float32)
-        for j, i in enumerate(my_pwms):
-            for q in range(W):
-                pw0[j, q, (int(seed_ids[i]) >> (2 * q)) & 3] = 0.7
-        pw_init = torch.from_numpy(pw0).to(dev)
+
+        def seed_pwms(ids):
+            pw = np.full((max(len(ids), 1), W, 4), 0.1, np.float32)
+            for j, x in enumerate(ids):
+                for q in range(W):
+                    pw[j, q, (int(x) >> (2 * q)) & 3] = 0.7
+            return pw
+
+        pw_init = torch.from_numpy(seed_pwms([seed_ids[i] for i in my_pwms])).to(dev)
         pwms = torch.empty_like(pw_init)
         em_state = torch.zeros((max(n_my, 1), 2), dtype=torch.int32, device=dev)
         em_change = torch.zeros(max(n_my, 1), dtype=torch.float32, device=dev)
@@ -128,7 +187,12 @@ def main():
 
         ev = {k: [ctx.timer(), ctx.timer()] for k in ("count", "sweep", "em")}
         acc = {k: 0.0 for k in ev}
-        pending = []
+
+        def exchange():
+            if rccl_ranks > 1:  # the ONE exchange step (C1)
+                pk._check(lib.pengk_allreduce_tables(ctx.h, W, counts.data_ptr(), scal[84:].data_ptr(), scal.data_ptr()))
+            else:               # no-op at N = 1; gloo rehearsal otherwise
+                sharding.allreduce_tables(counts, scal, dist)
 
         def step(timed):
             if timed:
@@ -137,7 +201,7 @@ def main():
             pk._check(lib.pengk_count_bg(ctx.h, int(both), counts.data_ptr(), scal[84:].data_ptr(), scal.data_ptr()))
             if timed:
                 ctx.record(ev["count"][1])
-            sharding.allreduce_tables(counts, scal, dist)  # the ONE exchange step (C1); no-op at N = 1
+            exchange()
             if both:
                 pk._check(lib.pengk_mirror_counts(ctx.h, W, counts.data_ptr()))
             pk._check(lib.pengk_bg_model(ctx.h, scal.data_ptr(), K, alpha.ctypes.data, V.data_ptr()))
@@ -174,46 +238,75 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
 
-        # ---- EM-only stress (BASELINE configs[4]): many seed PWMs on the table the last step left -------------
-        em_stress = None
-        if args.em_stress_pwms > 0:
-            n_st = len([i for i in range(args.em_stress_pwms) if i % world == rank])
-            ids = rng.integers(0, NP, size=max(n_st, 1))
-            ps0 = np.full((max(n_st, 1), W, 4), 0.1, np.float32)
-            for j in range(n_st):
-                for q in range(W):
-                    ps0[j, q, (int(ids[j]) >> (2 * q)) & 3] = 0.7
-            ps_init = torch.from_numpy(ps0).to(dev)
-            ps = torch.empty_like(ps_init)
-            st_state = torch.zeros((max(n_st, 1), 2), dtype=torch.int32, device=dev)
-            st_change = torch.zeros(max(n_st, 1), dtype=torch.float32, device=dev)
+        def time_em(mode, n, init, out, state, change, reps=2):
+            if not n:
+                return None
+            ctx.set_option("em_fast", mode)
             t_a, t_b = ctx.timer(), ctx.timer()
             best = None
-            for rep in range(3):
-                ps.copy_(ps_init)
+            for _ in range(reps):
+                out.copy_(init)
                 ctx.record(t_a)
-                if n_st:
-                    pk._check(lib.pengk_em_device(ctx.h, W, n_st, ps.data_ptr(), 1e4, 0.0, args.em_iters, counts.data_ptr(),
-                                                  bgprob[K].data_ptr(), st_state.data_ptr(), st_change.data_ptr()))
+                pk._check(lib.pengk_em_device(ctx.h, W, n, out.data_ptr(), 1e4, 0.0, args.em_iters, counts.data_ptr(),
+                                              bgprob[K].data_ptr(), state.data_ptr(), change.data_ptr()))
                 ctx.record(t_b)
                 ms = ctx.elapsed_ms(t_a, t_b)
                 best = ms if best is None else min(best, ms)
-            em_stress = (n_st, best)
+            ctx.set_option("em_fast", args.em_fast)
+            return best
 
-        # ---- the bit-exact serial EM mode (what the CLI runs) on the step's own PWM batch, for the record ----------------
-        em_serial_ms = None
-        if n_my and args.em_fast != 2:
+        checks = None
+        if args.checks:  # what a 1-rank run of the same global set must reproduce bit for bit (serial EM: no batching effects)
             ctx.set_option("em_fast", 2)
-            t_a, t_b = ctx.timer(), ctx.timer()
-            for rep in range(2):
-                pwms.copy_(pw_init)
-                ctx.record(t_a)
+            pwms.copy_(pw_init)
+            if n_my:
                 pk._check(lib.pengk_em_device(ctx.h, W, n_my, pwms.data_ptr(), 1e4, 0.0, args.em_iters, counts.data_ptr(),
                                               bgprob[K].data_ptr(), em_state.data_ptr(), em_change.data_ptr()))
-                ctx.record(t_b)
-                ms = ctx.elapsed_ms(t_a, t_b)
-                em_serial_ms = ms if em_serial_ms is None else min(em_serial_ms, ms)
             ctx.set_option("em_fast", args.em_fast)
+            torch.cuda.synchronize()
+            mine = {int(i): pwms[j].cpu().numpy().tobytes().hex() for j, i in enumerate(my_pwms)}
+            allp = [mine]
+            if world > 1:
+                allp = [None] * world
+                dist.all_gather_object(allp, mine)
+            merged = {}
+            for d_ in allp:
+                merged.update(d_)
+            checks = {"sha_counts": sha(counts.cpu().numpy()), "sha_z": sha(z.cpu().numpy()), "sha_bg_ltot": sha(scal.cpu().numpy()),
+                      "sha_em_pwms": hashlib.sha256("".join(merged[i] for i in sorted(merged)).encode()).hexdigest()}
+
+        # the other EM mode on the step's own PWM batch, for the record
+        other_mode = 1 if args.em_fast == 2 else 2
+        em_other_ms = time_em(other_mode, n_my, pw_init, pwms, em_state, em_change)
+
+        # ---- EM-only stress, BASELINE configs[4] as SURVEY.md 8(d) defines it: PLUS count table of this input, the
+        #      highest-count k-mers (ties by ascending id) as seeds, threshold 0, all iterations ----------------------
+        em_stress = None
+        stress_probe = None
+        if args.em_stress_pwms > 0:
+            pk._check(lib.pengk_count_bg(ctx.h, 0, counts.data_ptr(), scal[84:].data_ptr(), scal.data_ptr()))
+            exchange()
+            pk._check(lib.pengk_bg_model(ctx.h, scal.data_ptr(), K, alpha.ctypes.data, V.data_ptr()))
+            pk._check(lib.pengk_pattern_stats(ctx.h, W, 0, K, K, V.data_ptr(), scal[84:].data_ptr(), counts.data_ptr(),
+                                              bgprob.data_ptr(), expected.data_ptr(), logp.data_ptr(), z.data_ptr()))
+            torch.cuda.synchronize()
+            c_host = counts.cpu().numpy().view(np.uint32)
+            top = np.lexsort((np.arange(NP), -c_host.astype(np.int64)))[:args.em_stress_pwms]
+            mine_s = [int(x) for i, x in enumerate(top) if i % world == rank]
+            n_st = len(mine_s)
+            ps_init = torch.from_numpy(seed_pwms(mine_s)).to(dev)
+            ps = torch.empty_like(ps_init)
+            st_state = torch.zeros((max(n_st, 1), 2), dtype=torch.int32, device=dev)
+            st_change = torch.zeros(max(n_st, 1), dtype=torch.float32, device=dev)
+            ms_fast = time_em(1, n_st, ps_init, ps, st_state, st_change, reps=3)
+            if rank == 0 and n_st:  # handed to the CPU-baseline leg, which checks PWM 0 against the oracle
+                torch.cuda.synchronize()
+                stress_probe = dict(counts=c_host.copy(), bg=bgprob[K].cpu().numpy(), seed=mine_s[0], pwm=ps[0].cpu().numpy())
+            ms_serial = time_em(2, n_st, ps_init, ps, st_state, st_change, reps=1)
+            em_stress = (n_st, ms_fast, ms_serial)
+            # back to the step's tables for the K4 probe
+            step(False)
+            torch.cuda.synchronize()
 
         # ---- K4 probe (not part of the step): the mutants of one hill-climb round, 1 .. 6 degenerate letters each ----
         k4 = None
@@ -256,28 +349,37 @@ def main():
         # algorithmic bytes of K1 per launch: packed payload + 8 B per scan item + the count table
         alg_bytes = (nseq * L + 3) // 4 + 8 * int(ni.value) + 4 * NP
         achieved = alg_bytes / (count_ms * 1e-3) / 1e9 if count_ms > 0 else 0.0
+        mode_name = {0: "reference terms, fp64 tree sums (1e-5 rel.)", 1: "one reciprocal per weight, fp64 tree sums (1e-5 rel., BASELINE.json's bar)",
+                     2: "serial float32 in the reference's order, bit-exact (the peng_motif CLI's mode)"}
+        step_other_ms = (ms_per_step - em_ms + em_other_ms) if em_other_ms is not None else None
         out = {
             "metric": "4^W pattern z-scores/s + EM PWM-kmer evals/s at W=10; Gbp/s k-mer count",
             "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 counts / f32 scores / f64 EM accumulators", "data": "synthetic",
+            "dtype": "u32 counts / f32 scores / f32 serial EM sums (f64 tree sums in the throughput EM mode)", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d bp per GPU, W=%d, %s strands, bg-order 2 (BASELINE configs[2]); step = count + all-reduce + sweep + EM(%d PWMs x %d it)"
                        % (nseq, L, W, "both" if both else "plus", P_total, args.em_iters),
                        "n_seq_per_gpu": nseq, "seq_len": L, "W": W, "strand": args.strand, "ltot_global": ltot,
                        "parallelism": "sequence shards x%d, one all-reduce of the 4^W counts" % world,
-                       "em_mode": {0: "reference terms, fp64 tree sums (1e-5 rel.)", 1: "one reciprocal per weight, fp64 tree sums (1e-5 rel., BASELINE.json's bar)",
-                                   2: "serial float32, bit-exact"}[args.em_fast]
-                                  + "; the bit-exact serial mode the CLI uses is timed separately: components.em_serial_mode_ms"},
+                       "exchange": ("RCCL, %d ranks, pengk_allreduce_tables on the kernels' stream" % rccl_ranks) if rccl_ranks > 1
+                       else ("none (one rank)" if world == 1 else "gloo rehearsal through the host (not a measured configuration)"),
+                       "em_mode": mode_name[args.em_fast]},
             "components": {
                 "count_gbp_per_s_per_gpu": round(nseq * L / (count_ms * 1e-3) / 1e9, 3) if count_ms else None,
                 "zscores_per_s": round(NP / (sweep_ms * 1e-3), 1) if sweep_ms else None,
                 "em_evals_per_s_per_gpu": round(n_my * args.em_iters * NP / (em_ms * 1e-3), 1) if em_ms and n_my else None,
                 "count_ms": round(count_ms, 4), "sweep_ms": round(sweep_ms, 4), "em_ms": round(em_ms, 4),
+                # the step's EM batch in the other mode (1 = throughput mode when the step runs the serial one), and
+                # what the step would take with it
+                "em_other_mode": other_mode, "em_other_mode_ms": round(em_other_ms, 4) if em_other_ms is not None else None,
+                "step_ms_with_other_em_mode": round(step_other_ms, 4) if step_other_ms is not None else None,
+                "value_with_other_em_mode": round(total_bases / (step_other_ms * 1e-3) / 1e9, 4) if step_other_ms else None,
+                # BASELINE configs[4]: top-count seeds of the PLUS table, threshold 0
                 "em_stress_pwms_per_gpu": em_stress[0] if em_stress else None,
-                "em_stress_ms": round(em_stress[1], 4) if em_stress else None,
+                "em_stress_ms": round(em_stress[1], 4) if em_stress and em_stress[1] else None,
                 "em_stress_evals_per_s_per_gpu": round(em_stress[0] * args.em_iters * NP / (em_stress[1] * 1e-3), 1)
                 if em_stress and em_stress[1] else None,
-                "em_serial_mode_ms": round(em_serial_ms, 4) if em_serial_ms else None,
+                "em_stress_serial_mode_ms": round(em_stress[2], 4) if em_stress and em_stress[2] else None,
                 # K4 (host call incl. id upload, result download and the libm epilogue): patterns and underlying k-mers
                 "k4_patterns": k4[0] if k4 else None, "k4_ms": round(k4[2] * 1e3, 4) if k4 else None,
                 "k4_kmers_visited_per_s": round(k4[1] / k4[2], 1) if k4 else None,
@@ -292,49 +394,153 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        # HBM traffic and issue counters are NOT measured in this run (they need rocprofv3 --pmc passes): copied from the
+        # committed profile, with the commit and the configuration they were taken at
         prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(prof):
             try:
-                out["roofline"]["traffic"] = json.load(open(prof)).get("count_kernel_hbm_bytes_per_launch")
+                pj = json.load(open(prof))
+                out["roofline"]["traffic"] = pj.get("count_kernel_hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = "profiles/traffic_latest.json: rocprofv3 --pmc passes at commit %s (%s), not this run" % (
+                    pj.get("commit", "?"), pj.get("config", "config 3"))
+                if "issue" in pj:  # second roofline of K1: the pass-A kernel is bound by instruction issue, not by bytes
+                    out["roofline_issue"] = pj["issue"]
             except Exception:
                 pass
+        if em_stress and em_stress[1]:
+            evals = em_stress[0] * args.em_iters * NP / (em_stress[1] * 1e-3)
+            out["roofline_em"] = {
+                "kernel": "em_accumulate_kernel<%d,...> (K5, throughput mode, %d PWMs x %d iterations)" % (W, em_stress[0], args.em_iters),
+                "bound": "fp32 vector issue", "flop_per_eval": 2 * W + 4, "bytes_per_eval": 8,
+                "achieved": round(evals * (2 * W + 4) / 1e12, 3), "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(evals * (2 * W + 4) / 1e12 / FP32_VECTOR_PEAK_TF, 5),
+                "table_stream_gb_per_s": round(evals * 8 / 1e9, 1), "table_stream_frac_of_hbm_peak": round(evals * 8 / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "8 B per evaluation (u32 count + f32 background) streamed per PWM from L2 / Infinity Cache (the 8 MB of tables stay on die), so the byte rate may exceed the HBM peak; 2W+4 flop per evaluation as SURVEY.md 8(d) counts them"}
+        if checks:
+            out["checks"] = checks
+        if world == 1 and not args.no_e2e:
+            out["components"]["e2e_cli"] = e2e_cli(args, W, both, L, nseq)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, W, both, L)
+            out["cpu_baseline"] = cpu_baseline(args, W, both, L, stress_probe)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, W, both, L):
-    """The oracle (bit-exact restatement of the reference's serial loops) timed on one host core on a
-    bounded sample of the same workload: count over `cpu_sample_seqs` sequences, the sweep over all 4^W
-    patterns, one EM iteration of 4 PWMs."""
+def e2e_cli(args, W, both, L, nseq):
+    """End to end: the config's FASTA on disk -> peng-motif_amd/host/peng_motif (PENGK_TIMING=1) -> MEME + JSON, wall clock
+    of the process and the phases it reports, beside BASELINE.md's figure for the reference (277.3 s at 10M x 200 bp, W=10,
+    1 thread, survey container)."""
+    exe = os.path.join(ROOT, "peng-motif_amd", "host", "peng_motif")
+    gen = os.path.join(ROOT, "tools", "synth_fasta")
+    if not (os.path.exists(exe) and os.path.exists(gen)):
+        return {"error": "peng_motif / synth_fasta not built"}
+    import shutil
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 4 * nseq * (L + 12) else None
+    tmp = tempfile.mkdtemp(prefix="pengk_e2e_", dir=base)
+    try:
+        fa = os.path.join(tmp, "s.fa")
+        t0 = time.perf_counter()
+        subprocess.run([gen, fa, str(nseq), str(L), "1", "0"], check=True, timeout=600)
+        t_gen = time.perf_counter() - t0
+        cmd = [exe, fa, "-w", str(W), "--strand", "BOTH" if both else "PLUS", "-o", os.path.join(tmp, "o.meme"), "-j",
+               os.path.join(tmp, "o.json")]
+        best = None
+        for rep in range(2):  # second run: page cache and GPU code objects warm, like the reference's timing in the survey
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, PENGK_TIMING="1"),
+                               timeout=900)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": "peng_motif exited %d: %s" % (r.returncode, r.stderr.decode()[-300:])}
+            phases = {}
+            for line in r.stderr.decode().split("\n"):
+                if line.startswith("[timing] ") and ": " in line:
+                    k_, v_ = line[len("[timing] "):].rsplit(": ", 1)
+                    phases[k_.strip()] = float(v_.split()[0])
+            if best is None or wall < best[0]:
+                best = (wall, phases)
+        n_motifs = sum(1 for l in open(os.path.join(tmp, "o.meme")) if l.startswith("MOTIF"))
+        return {"wall_s": round(best[0], 3), "phases_s": best[1], "motifs": n_motifs, "fasta_bytes": os.path.getsize(fa),
+                "fasta_generation_s": round(t_gen, 2), "command": "peng_motif s.fa -w %d --strand %s -o o.meme -j o.json" % (W, "BOTH" if both else "PLUS"),
+                "reference_wall_s_baseline_md": 277.3 if (nseq, L, W, both) == (10_000_000, 200, 10, True) else None,
+                "speedup_vs_baseline_md": round(277.3 / best[0], 1) if (nseq, L, W, both) == (10_000_000, 200, 10, True) else None}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline(args, W, both, L, stress_probe=None):
+    """CPU side of the same run, on this box's host cores, on bounded samples of the same workload:
+      * the oracle (bit-exact restatement of the reference's serial loops, g++ -O3, one thread): count, bg counts,
+        bgprob tables, sweep, seed selection, EM;
+      * the compiled reference itself (oracle/_ref, when it travelled with the repository): its BasePattern constructor
+        on a sample, and the whole CLI on a sample with every phase of SURVEY.md 8(d) taken from the time its stdout
+        banners arrive -- once with 1 thread, once with all cores (count and EM are serial in the reference)."""
     from oracle import oracle as po
     n = args.cpu_sample_seqs
+    t0 = time.perf_counter()
     codes, offs = po.synth(1, 0, n, L)
     t0 = time.perf_counter()
     counts, ltot = po.count(codes, offs, W, both)
     t_count = time.perf_counter() - t0
-    V = po.bg_V(po.bg_counts(codes[: 2000 * L], offs[:2001], 2), 2)
-    nsweep = 10
+    t0 = time.perf_counter()
+    nb = po.bg_counts(codes, offs, 2)
+    t_bgc = time.perf_counter() - t0
+    V = po.bg_V(nb, 2)
+    t0 = time.perf_counter()
+    bgp = [po.bgprob(W, k, V, both) for k in range(3)]
+    t_bgp = time.perf_counter() - t0
+    nsweep = 5
     t0 = time.perf_counter()
     for _ in range(nsweep):
-        bgp = [po.bgprob(W, k, V, both) for k in range(3)]
         e, lp, z = po.stats(W, counts, bgp[2], ltot)
-    t_sweep = (time.perf_counter() - t0) / nsweep
+    t_stats = (time.perf_counter() - t0) / nsweep
+    t0 = time.perf_counter()
+    seeds = po.select(W, z, counts, 10.0, 3, not both, True)
+    t_select = time.perf_counter() - t0
     pw = np.full((W, 4), 0.1, np.float32)
     pw[:, 0] = 0.7
     t0 = time.perf_counter()
-    npw = 30
+    npw = 20
     for _ in range(npw):
         po.em(W, counts, bgp[2], pw, 1e4, 0.0, 10, mode=0)
     t_em = time.perf_counter() - t0
-    extra = reference_probe(W, both, L)
-    return {"value": round(n * L / t_count / 1e9, 5), "unit": "Gbp/s", "cores": 1, "kind": "port", **extra,
-            "sample": "oracle (bit-exact port of the reference's serial loops, g++ -O3, 1 thread) on %d x %d bp of the same synthetic set: count %.2f s; %d sweeps over 4^%d patterns %.3f s each; %d PWMs x 10 EM iterations %.2f s"
-                      % (n, L, t_count, nsweep, W, t_sweep, npw, t_em),
-            "zscores_per_s": round(4 ** W / t_sweep, 1), "em_evals_per_s": round(npw * 10 * 4 ** W / t_em, 1)}
+    out = {"value": round(n * L / t_count / 1e9, 5), "unit": "Gbp/s", "cores": 1, "kind": "port",
+           "sample": "oracle (bit-exact port of the reference's serial loops, g++ -O3, 1 thread) on %d x %d bp of the same synthetic set: count %.2f s; sweep over 4^%d patterns %.3f s; %d PWMs x 10 EM iterations %.2f s"
+                     % (n, L, t_count, W, t_stats, npw, t_em),
+           "zscores_per_s": round(4 ** W / t_stats, 1), "em_evals_per_s": round(npw * 10 * 4 ** W / t_em, 1),
+           "port_phases_s": {"count": round(t_count, 3), "bg_counts": round(t_bgc, 3), "bgprob_tables_3_orders": round(t_bgp, 3),
+                             "stats_sweep": round(t_stats, 4), "seed_selection_%d_seeds" % len(seeds): round(t_select, 3),
+                             "em_per_pwm_10_iterations": round(t_em / npw, 4), "sample_sequences": n}}
+    if stress_probe is not None:  # BASELINE configs[4] spot check: PWM 0 of the stress batch against the fp64 restatement
+        ref, it, _ = po.em(W, stress_probe["counts"].astype(np.uint64), stress_probe["bg"],
+                           _seed_pwm(stress_probe["seed"], W), 1e4, 0.0, 10, mode=1, final_norm=False)
+        dev = float(np.abs(stress_probe["pwm"].astype(np.float64) - ref).max())
+        out["em_stress_check"] = {"seed": po.kmer_str(stress_probe["seed"], W), "max_abs_dev_vs_fp64_oracle": dev, "ok": bool(dev <= 1e-6)}
+    out.update(reference_probe(W, both, L))
+    out.update(reference_cli_phases(W, both, L))
+    return out
+
+
+def _seed_pwm(x, W):
+    pw = np.full((W, 4), 0.1, np.float32)
+    for q in range(W):
+        pw[q, (int(x) >> (2 * q)) & 3] = 0.7
+    return pw
+
+
+def _write_sample_fasta(path, n, L):
+    gen = os.path.join(ROOT, "tools", "synth_fasta")
+    if os.path.exists(gen):
+        subprocess.run([gen, path, str(n), str(L), "1", "0"], check=True, timeout=600)
+        return
+    from oracle import oracle as po
+    codes, _ = po.synth(1, 0, n, L)
+    rows = np.frombuffer(b"NACGT", dtype=np.uint8)[codes].reshape(n, L)
+    with open(path, "wb") as f:
+        f.write(b"".join((">s%d\n" % i).encode() + rows[i].tobytes() + b"\n" for i in range(n)))
 
 
 def reference_probe(W, both, L, n=400_000):
@@ -345,25 +551,67 @@ def reference_probe(W, both, L, n=400_000):
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
     if not os.path.exists(exe):
         return {}
-    import subprocess
+    import shutil
     import tempfile
-    from oracle import oracle as po
+    tmp = tempfile.mkdtemp(prefix="pengk_refprobe_")
     try:
-        tmp = tempfile.mkdtemp(prefix="pengk_refprobe_")
-        codes, _ = po.synth(1, 0, n, L)
-        rows = np.frombuffer(b"NACGT", dtype=np.uint8)[codes].reshape(n, L)
-        with open(os.path.join(tmp, "s.fa"), "wb") as f:
-            f.write(b"".join((">s%d\n" % i).encode() + rows[i].tobytes() + b"\n" for i in range(n)))
+        _write_sample_fasta(os.path.join(tmp, "s.fa"), n, L)
         subprocess.run([exe, os.path.join(tmp, "s.fa"), str(W), "BOTH" if both else "PLUS", tmp, "tables"], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
         meta = dict(l.split() for l in open(os.path.join(tmp, "meta.txt")))
         t = float(meta["basepattern_seconds"])
-        import shutil
-        shutil.rmtree(tmp, ignore_errors=True)
         return {"reference_basepattern_gbp_per_s": round(n * L / t / 1e9, 5),
                 "reference_sample": "compiled reference (oracle/_ref, g++ -O3, 1 thread): BasePattern constructor on %d x %d bp in %.2f s" % (n, L, t)}
     except Exception as e:  # the probe is optional
         return {"reference_sample": "probe failed: %r" % (e,)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def reference_cli_phases(W, both, L, n=300_000):
+    """The compiled reference CLI (oracle/_ref/peng_motif_ref) on a sample, phases from the arrival times of its stdout
+    banners (src/peng.cpp:315-320): ingest + background model | BasePattern (bgprob, count, stats) | seed selection |
+    IUPAC optimisation | filter + PWMs | EM + merging + output.  Once with --threads 1 and once with all cores (its
+    OpenMP loops are the sweeps and the hill-climb; count and EM are serial)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "peng_motif_ref")
+    if not os.path.exists(exe):
+        return {"reference_cli_phases": "oracle/_ref/peng_motif_ref not present on this box"}
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="pengk_refcli_")
+    marks = [("[STATUS] Processing kmers", "ingest_x2_and_background_model"), ("[STATUS] Finding overrepresented", "basepattern_bgprob_count_stats"),
+             ("[STATUS] Optimizing base patterns", "seed_selection"), ("[STATUS] Filtering degenerated", "iupac_optimisation"),
+             ("[STATUS] Calculating PWMs", "filter"), ("[STATUS] Optimizing expectation", "pwm_construction")]
+    try:
+        fa = os.path.join(tmp, "s.fa")
+        _write_sample_fasta(fa, n, L)
+        res = {}
+        cores = os.cpu_count() or 1
+        for threads in (1, cores):
+            t0 = time.perf_counter()
+            p = subprocess.Popen([exe, fa, "-w", str(W), "--strand", "BOTH" if both else "PLUS", "--threads", str(threads), "-o",
+                                  os.path.join(tmp, "o.meme")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+            last, phases, idx = t0, {}, 0
+            for raw in p.stdout:
+                line = raw.decode(errors="replace")
+                if idx < len(marks) and line.startswith(marks[idx][0]):
+                    now = time.perf_counter()
+                    phases[marks[idx][1]] = round(now - last, 3)
+                    last = now
+                    idx += 1
+            p.wait(timeout=900)
+            now = time.perf_counter()
+            phases["em_merging_output"] = round(now - last, 3)
+            phases["total"] = round(now - t0, 3)
+            res["threads_%d" % threads] = phases
+            if threads == cores:
+                break
+        return {"reference_cli_phases": res, "reference_cli_sample": "compiled reference CLI on %d x %d bp of the same synthetic set, W=%d, host cores %d"
+                % (n, L, W, cores)}
+    except Exception as e:
+        return {"reference_cli_phases": "failed: %r" % (e,)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -231,7 +231,7 @@ int pengk_comm_destroy(pengk_ctx* ctx) {
 int pengk_allreduce_tables(pengk_ctx* ctx, int W, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg) {
   if (!ctx || !d_counts || !d_ltot) return fail(PENGK_ERR_ARG, "pengk_allreduce_tables: NULL argument");
   if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
-  if (!ctx->comm || ctx->comm_world == 1) return PENGK_OK;  // one rank: the tables are already global
+  if (!ctx->comm) return PENGK_OK;  // no communicator: the tables are already global (a 1-rank communicator still runs RCCL)
   int rc = enter(ctx);
   if (rc) return rc;
   const size_t np = (size_t)1 << (2 * W);
@@ -248,7 +248,7 @@ int pengk_comm_check_bin_bound(pengk_ctx* ctx) {
   if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
   if (!ctx->d_words) return fail(PENGK_ERR_ARG, "pengk_comm_check_bin_bound: no sequences attached");
   uint64_t bound = ctx->max_bin_bound;
-  if (ctx->comm && ctx->comm_world > 1) {
+  if (ctx->comm) {
     int rc = enter(ctx);
     if (rc) return rc;
     rc = ensure_scratch(ctx, &ctx->d_misc, &ctx->misc_bytes, sizeof(uint64_t));
@@ -268,7 +268,7 @@ int pengk_allgather(pengk_ctx* ctx, const void* d_send, void* d_recv, size_t byt
   if (!ctx || !d_send || !d_recv) return fail(PENGK_ERR_ARG, "pengk_allgather: NULL argument");
   int rc = enter(ctx);
   if (rc) return rc;
-  if (!ctx->comm || ctx->comm_world == 1) {
+  if (!ctx->comm) {
     if (d_send != d_recv) PENGK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
     return PENGK_OK;
   }

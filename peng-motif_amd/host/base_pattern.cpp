@@ -50,7 +50,7 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
   // ---- K1 count (+ twin copy), K2+K3 sweep ---------------------------------------------------------------
   d_counts.resize(NP);
   check(pengk_count(context(), both, d_counts.get(), d_ltot.get()), "pengk_count");
-  if (n_ranks > 1) {
+  if (pengk_host::launched()) {
     // C1, the one exchange step: shard counts add exactly (the non-overlap rule is per sequence, src/base_pattern.cpp:382).
     // The 32-bit bins must hold the GLOBAL counts: the bound is all-reduced and checked first.
     check(pengk_comm_check_bin_bound(context()), "pengk_comm_check_bin_bound");

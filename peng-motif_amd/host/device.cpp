@@ -1,6 +1,9 @@
 #include "device.h"
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -20,11 +23,15 @@ int world() {
   static const int w = std::max(1, env_int("WORLD_SIZE", 1));
   return w;
 }
+bool launched() {
+  static const bool l = std::getenv("WORLD_SIZE") != nullptr;
+  return l;
+}
 int rank() {
-  static const int r = world() > 1 ? env_int("RANK", 0) : 0;
+  static const int r = launched() ? env_int("RANK", 0) : 0;
   return r;
 }
-static int device_index() { return world() > 1 ? env_int("LOCAL_RANK", rank()) : Global::device; }
+static int device_index() { return launched() && std::getenv("LOCAL_RANK") ? env_int("LOCAL_RANK", 0) : Global::device; }
 
 void shard_range(size_t n, int r, int w, size_t* lo, size_t* hi) {
   const size_t base = n / (size_t)w, rem = n % (size_t)w;
@@ -75,7 +82,21 @@ pengk_ctx* context() {
     int mode = 2;
     if (const char* e = std::getenv("PENGK_EM_FAST")) mode = std::atoi(e);
     check(pengk_set_option(g_ctx, "em_fast", mode), "pengk_set_option");
-    if (world() > 1) check(pengk_comm_init_env(g_ctx), "pengk_comm_init_env");  // RCCL over xGMI; collective: every rank gets here
+    if (launched()) {  // RCCL over xGMI; collective: every rank gets here
+      // librccl announces its version on stdout while the communicator is built; stdout is the reference's trace
+      // (compared byte for byte), so that line goes to stderr
+      std::cout.flush();
+      fflush(stdout);
+      const int saved = dup(1);
+      if (saved >= 0) dup2(2, 1);
+      const int rc = pengk_comm_init_env(g_ctx);
+      fflush(stdout);
+      if (saved >= 0) {
+        dup2(saved, 1);
+        close(saved);
+      }
+      check(rc, "pengk_comm_init_env");
+    }
   }
   return g_ctx;
 }

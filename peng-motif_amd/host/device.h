@@ -24,6 +24,7 @@ void check(int rc, const char* what);
 // carries an RCCL communicator (pengk_comm_init_env).  Without a launcher: rank 0 of 1.
 int rank();
 int world();
+bool launched();  // WORLD_SIZE is set (even to 1): the run goes through the communicator
 // contiguous whole-record shard [lo, hi) of rank r: sizes differ by at most one
 void shard_range(size_t n, int r, int w, size_t* lo, size_t* hi);
 

@@ -66,7 +66,7 @@ void Peng::em_optimize_pwms(std::vector<IUPACPattern*>& patterns, BasePattern* b
     for (size_t p = 0; p < W; ++p)
       for (int a = 0; a < 4; ++a) pw[(i * W + p) * 4 + a] = patterns[i]->get_pwm()[p][a];
   const int n_ranks = pengk_host::world(), me = pengk_host::rank();
-  if (n && n_ranks == 1) {
+  if (n && !pengk_host::launched()) {
     pengk_host::check(pengk_em(pengk_host::context(), (int)W, (int64_t)n, pw.data(), saturation_factor, min_em_threshold,
                                max_iterations, base_patterns->device_counts(), base_patterns->device_bgprob(background_order),
                                nullptr, nullptr),

@@ -21,7 +21,7 @@ def last_json(out):
 def test_single_rank_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--nseq", "200000",
                         "--cpu-sample-seqs", "20000", "--em-stress-pwms", "32"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       timeout=600)
+                       timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = last_json(r.stdout)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -33,7 +33,14 @@ def test_single_rank_json_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["em_stress_check"]["ok"], cb["em_stress_check"]  # configs[4] seeds: PWM 0 against the fp64 oracle
+    for phase in ("count", "bg_counts", "bgprob_tables_3_orders", "stats_sweep", "em_per_pwm_10_iterations"):
+        assert cb["port_phases_s"][phase] > 0
     assert d["value"] > 0 and abs(d["value"] - 200000 * 200 / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-2 * d["value"]
+    assert "serial" in d["config"]["em_mode"] and d["components"]["em_other_mode"] == 1  # the step runs the CLI's EM mode
+    assert d["roofline_em"]["flop_per_eval"] == 24 and d["roofline_em"]["frac"] > 0
+    e2e = d["components"]["e2e_cli"]
+    assert "error" not in e2e and e2e["wall_s"] > 0 and e2e["motifs"] >= 1 and "total" in e2e["phases_s"]
 
 
 def test_two_rank_rehearsal_allreduces_the_tables():
@@ -51,3 +58,90 @@ def test_two_rank_rehearsal_allreduces_the_tables():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
     assert d["config"]["ltot_global"] == 2 * 150000 * 191  # both shards arrived in the reduced ltot
     assert abs(d["value"] - 2 * 150000 * 200 / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-2 * d["value"]
+
+
+def _bench(extra, env=None, launcher=None):
+    cmd = ([sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--em-stress-pwms", "0",
+                                                  "--k4-patterns", "0", "--no-cpu-baseline", "--no-e2e", "--checks"] + extra)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return last_json(r.stdout)
+
+
+def test_two_ranks_through_the_hip_path_reproduce_one_rank_bit_for_bit():
+    """Two ranks, each counting its 150k-sequence shard ON THE GPU, after the exchange step hold the tables a single
+    rank computes from the 300k sequences: sha256 of the count table, of {bg counters, ltot}, of z and of the gathered
+    serial-mode EM PWMs are equal.  (gloo carries the exchange here -- RCCL cannot put two ranks on the box's one GPU;
+    the RCCL calls themselves are covered by test_rccl_single_rank_communicator and by the N > 1 bench runs.)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    two = _bench(["--gpus", "2", "--nseq", "150000"], env=dict(os.environ, PENGK_BENCH_BACKEND="gloo"),
+                 launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port)])
+    one = _bench(["--nseq", "300000"])
+    assert two["config"]["ltot_global"] == one["config"]["ltot_global"] == 300000 * 191
+    assert two["checks"] == one["checks"], (two["checks"], one["checks"])
+
+
+def test_gpus_flag_must_match_the_launch():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and b"--gpus 3" in r.stderr
+
+
+def test_rccl_single_rank_communicator():
+    """The C++ exchange step against the real librccl on the GPU box: a 1-rank communicator (all RCCL allows on one GPU)
+    runs the grouped all-reduce, the bin-bound collective and the all-gather through RCCL and leaves the data unchanged."""
+    import ctypes as C
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    import peng_motif_amd as pk
+    lib = pk.lib()
+    ctx = pk.Context(0)
+    try:
+        W = 8
+        ctx.synth(3, 0, 5000, 120, W)
+        counts, ltot, bg = ctx.count_bg(True)
+        before = (counts.to_host().copy(), ltot.to_host().copy(), bg.to_host().copy())
+        idb = C.create_string_buffer(128)
+        pk._check(lib.pengk_comm_unique_id(idb))
+        pk._check(lib.pengk_comm_init(ctx.h, idb, 0, 1))
+        r_, w_ = C.c_int(-1), C.c_int(-1)
+        pk._check(lib.pengk_comm_info(ctx.h, C.byref(r_), C.byref(w_)))
+        assert (r_.value, w_.value) == (0, 1)
+        pk._check(lib.pengk_comm_check_bin_bound(ctx.h))
+        pk._check(lib.pengk_allreduce_tables(ctx.h, W, pk._ptr(counts), pk._ptr(ltot), pk._ptr(bg)))
+        ctx.synchronize()
+        assert np.array_equal(counts.to_host(), before[0]) and np.array_equal(ltot.to_host(), before[1])
+        assert np.array_equal(bg.to_host(), before[2])
+        src = pk.DeviceArray.from_host(ctx, np.arange(1000, dtype=np.float32))
+        dst = ctx.empty(1000, np.float32)
+        pk._check(lib.pengk_allgather(ctx.h, pk._ptr(src), pk._ptr(dst), 4000))
+        ctx.synchronize()
+        assert np.array_equal(dst.to_host(), np.arange(1000, dtype=np.float32))
+        assert lib.pengk_comm_init(ctx.h, idb, 0, 1) != 0  # a context carries one communicator
+        pk._check(lib.pengk_comm_destroy(ctx.h))
+    finally:
+        ctx.close()
+
+
+def test_cli_under_a_launcher_environment_equals_the_plain_run(tmp_path):
+    """peng_motif started with RANK=0 WORLD_SIZE=1 (a launcher's environment) builds its RCCL communicator, shards
+    (one shard), all-reduces and all-gathers through RCCL -- and prints what the plain run prints, byte for byte."""
+    cli = os.path.join(ROOT, "peng-motif_amd", "host", "peng_motif")
+    fa = os.path.join(ROOT, "tests", "golden", "MafK.fasta")
+    outs = []
+    for tag, extra in (("plain", {}), ("launched", {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                                     "MASTER_PORT": "29533"})):
+        meme, js = tmp_path / (tag + ".meme"), tmp_path / (tag + ".json")
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        env.update(extra)
+        r = subprocess.run([cli, fa, "-w", "10", "-o", str(meme), "-j", str(js)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append((r.stdout, meme.read_bytes(), js.read_bytes()))
+    assert outs[0] == outs[1]
