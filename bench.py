@@ -88,6 +88,13 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
+    # stdout carries the ONE JSON line and nothing else: librccl announces its version there while communicators are
+    # built (torch's and libpengk's), so file descriptor 1 points at stderr for the rest of the run and the line goes to
+    # a duplicate of the original
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import peng_motif_amd as pk
     from peng_motif_amd import sharding
@@ -422,7 +429,8 @@ def main():
             out["components"]["e2e_cli"] = e2e_cli(args, W, both, L, nseq)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, W, both, L, stress_probe)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
@@ -485,8 +493,9 @@ def cpu_baseline(args, W, both, L, stress_probe=None):
     t0 = time.perf_counter()
     counts, ltot = po.count(codes, offs, W, both)
     t_count = time.perf_counter() - t0
+    n_bg = min(n, 500_000)  # the restatement of Sequence.cpp's k-mer arrays is slow: a smaller sample
     t0 = time.perf_counter()
-    nb = po.bg_counts(codes, offs, 2)
+    nb = po.bg_counts(codes[: n_bg * L], offs[: n_bg + 1], 2)
     t_bgc = time.perf_counter() - t0
     V = po.bg_V(nb, 2)
     t0 = time.perf_counter()
@@ -511,7 +520,7 @@ def cpu_baseline(args, W, both, L, stress_probe=None):
            "sample": "oracle (bit-exact port of the reference's serial loops, g++ -O3, 1 thread) on %d x %d bp of the same synthetic set: count %.2f s; sweep over 4^%d patterns %.3f s; %d PWMs x 10 EM iterations %.2f s"
                      % (n, L, t_count, W, t_stats, npw, t_em),
            "zscores_per_s": round(4 ** W / t_stats, 1), "em_evals_per_s": round(npw * 10 * 4 ** W / t_em, 1),
-           "port_phases_s": {"count": round(t_count, 3), "bg_counts": round(t_bgc, 3), "bgprob_tables_3_orders": round(t_bgp, 3),
+           "port_phases_s": {"count": round(t_count, 3), "bg_counts_%d_sequences" % n_bg: round(t_bgc, 3), "bgprob_tables_3_orders": round(t_bgp, 3),
                              "stats_sweep": round(t_stats, 4), "seed_selection_%d_seeds" % len(seeds): round(t_select, 3),
                              "em_per_pwm_10_iterations": round(t_em / npw, 4), "sample_sequences": n}}
     if stress_probe is not None:  # BASELINE configs[4] spot check: PWM 0 of the stress batch against the fp64 restatement
@@ -579,9 +588,12 @@ def reference_cli_phases(W, both, L, n=300_000):
     import shutil
     import tempfile
     tmp = tempfile.mkdtemp(prefix="pengk_refcli_")
-    marks = [("[STATUS] Processing kmers", "ingest_x2_and_background_model"), ("[STATUS] Finding overrepresented", "basepattern_bgprob_count_stats"),
-             ("[STATUS] Optimizing base patterns", "seed_selection"), ("[STATUS] Filtering degenerated", "iupac_optimisation"),
-             ("[STATUS] Calculating PWMs", "filter"), ("[STATUS] Optimizing expectation", "pwm_construction")]
+    # a banner is printed when the phase it names STARTS: the time up to banner i belongs to the phase of banner i - 1
+    # ("Finding overrepresented kmers" precedes the BasePattern constructor and the seed selection)
+    marks = [("[STATUS] Processing kmers", "ingest_x2_and_background_model"), ("[STATUS] Finding overrepresented", None),
+             ("[STATUS] Optimizing base patterns", "basepattern_bgprob_count_stats_and_seed_selection"),
+             ("[STATUS] Filtering degenerated", "iupac_optimisation"), ("[STATUS] Calculating PWMs", "filter"),
+             ("[STATUS] Optimizing expectation", "pwm_construction"), ("merge:", "em")]
     try:
         fa = os.path.join(tmp, "s.fa")
         _write_sample_fasta(fa, n, L)
@@ -596,12 +608,13 @@ def reference_cli_phases(W, both, L, n=300_000):
                 line = raw.decode(errors="replace")
                 if idx < len(marks) and line.startswith(marks[idx][0]):
                     now = time.perf_counter()
-                    phases[marks[idx][1]] = round(now - last, 3)
-                    last = now
+                    if marks[idx][1]:
+                        phases[marks[idx][1]] = round(now - last, 3)
+                        last = now
                     idx += 1
             p.wait(timeout=900)
             now = time.perf_counter()
-            phases["em_merging_output"] = round(now - last, 3)
+            phases["em_merging_output" if idx < len(marks) else "merging_output"] = round(now - last, 3)
             phases["total"] = round(now - t0, 3)
             res["threads_%d" % threads] = phases
             if threads == cores:

@@ -34,8 +34,10 @@ def test_single_rank_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
     assert cb["em_stress_check"]["ok"], cb["em_stress_check"]  # configs[4] seeds: PWM 0 against the fp64 oracle
-    for phase in ("count", "bg_counts", "bgprob_tables_3_orders", "stats_sweep", "em_per_pwm_10_iterations"):
+    for phase in ("count", "bgprob_tables_3_orders", "stats_sweep", "em_per_pwm_10_iterations"):
         assert cb["port_phases_s"][phase] > 0
+    ref = cb["reference_cli_phases"]["threads_1"]  # the compiled reference travels with the repository (oracle/_ref)
+    assert ref["total"] > 0 and "ingest_x2_and_background_model" in ref
     assert d["value"] > 0 and abs(d["value"] - 200000 * 200 / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-2 * d["value"]
     assert "serial" in d["config"]["em_mode"] and d["components"]["em_other_mode"] == 1  # the step runs the CLI's EM mode
     assert d["roofline_em"]["flop_per_eval"] == 24 and d["roofline_em"]["frac"] > 0
