@@ -174,6 +174,18 @@ int pengk_pattern_stats(pengk_ctx* ctx, int W, int both_strands, int k, int max_
                         const uint64_t* d_ltot, const uint32_t* d_counts, float* d_bgprob, float* d_expected,
                         float* d_logp, float* d_z);
 
+/* ---- seed candidates (first half of BasePattern::select_base_patterns, src/base_pattern.cpp:443-515) ----------------
+ * The reference std::sorts all 4^W ids by z-score and walks the ranking down to the threshold (:458-466); only ids with
+ * z >= z_threshold and count >= count_threshold can become seeds.  This call compacts exactly those on the device
+ * (unordered) into h_ids / h_z (capacity entries each); *n_out = their number -- when it exceeds capacity only the
+ * first `capacity` found were copied and the caller retries with room for n_out.  The caller ranks the survivors.
+ * NOTE the ranking of EXACT z ties (every reverse-complement pair under both strands) is std::sort's in the reference,
+ * i.e. unspecified: a caller that ranks by (z descending, id ascending) reports the same seed set up to the strand a
+ * pair is named on.  The host mirror keeps the reference's ranking by default (host/ranked_prefix.h) and uses this
+ * call only on request (PENGK_SEED_SELECT=device). */
+int pengk_seed_candidates(pengk_ctx* ctx, int W, const float* d_z, const uint32_t* d_counts, float z_threshold,
+                          uint64_t count_threshold, uint32_t* h_ids, float* h_z, int64_t capacity, int64_t* n_out);
+
 /* ---- K4: IUPAC degenerate-pattern aggregation (IUPACPattern::aggregate_attributes_from_basepatterns
  *      and count_combined_occurences, src/iupac_pattern.cpp:331-473,806-833) -------------------- */
 typedef struct pengk_iupac_stats {
@@ -213,6 +225,21 @@ int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturati
 int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold,
                     int max_iterations, const uint32_t* d_counts, const float* d_bg, int32_t* d_state,
                     float* d_change);
+
+/* ---- motif similarity grid (Peng::merge_iupac_patterns' inner loops, src/peng.cpp:251-272, over
+ *      IUPACPattern::calculate_S, src/iupac_pattern.cpp:568-615) -------------------------------------------------
+ * n motifs: h_pwm / h_comp = n x PENGK_MAX_MOTIF_LEN x 4 floats (PWM and its reverse-complement PWM, rows beyond
+ * h_len[i] unused), h_sites[i] = the motif's site count (decides which of a pair is complemented, :592-597), h_bg = the
+ * 4 background letter frequencies.  For every pair (i, j), i < j, j >= first_new -- ordered j = first_new .. n-1, then
+ * i = 0 .. j-1 -- h_out receives max over strands (both_strands) and shifts with >= 6 overlapping columns of the score
+ * s (calculate_s, :551-566), -inf when no shift qualifies.  first_new = 0: the whole triangle; first_new = n - 1: the
+ * new motif against all others after a merge.
+ * The values are an fp64 evaluation rounded to float; the reference rounds every partial sum to float, so they agree
+ * to ~1e-4, NOT bit for bit.  Use: find the pairs that can be the maximum, evaluate those with the reference's
+ * arithmetic (the host mirror does exactly that with a margin of 2e-3). */
+#define PENGK_MAX_MOTIF_LEN 64
+int pengk_motif_similarity(pengk_ctx* ctx, int n, const float* h_pwm, const float* h_comp, const int32_t* h_len,
+                           const uint64_t* h_sites, int both_strands, const float* h_bg, int first_new, float* h_out);
 
 /* ---- C1: the one exchange step of a multi-GPU run (no counterpart in the reference, which is a single
  *      process).  One process per GPU; sequences shard by whole records; every rank counts its shard, then the

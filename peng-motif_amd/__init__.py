@@ -26,7 +26,7 @@ EXPORTS = [
     "pengk_memset", "pengk_host_alloc", "pengk_host_free", "pengk_timer_create", "pengk_timer_record", "pengk_timer_elapsed_ms", "pengk_timer_destroy",
     "pengk_pack", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
     "pengk_count", "pengk_count_bg", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
-    "pengk_iupac_aggregate", "pengk_em", "pengk_em_device",
+    "pengk_seed_candidates", "pengk_iupac_aggregate", "pengk_em", "pengk_em_device", "pengk_motif_similarity",
     "pengk_comm_unique_id", "pengk_comm_init", "pengk_comm_init_env", "pengk_comm_info", "pengk_comm_destroy",
     "pengk_allreduce_tables", "pengk_comm_check_bin_bound", "pengk_allgather",
 ]
@@ -92,9 +92,11 @@ def lib():
         L.pengk_bg_count.argtypes = [vp, vp]
         L.pengk_bg_model.argtypes = [vp, vp, C.c_int, vp, vp]
         L.pengk_pattern_stats.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+        L.pengk_seed_candidates.argtypes = [vp, C.c_int, vp, vp, f32, u64, vp, vp, i64, C.POINTER(i64)]
         L.pengk_iupac_aggregate.argtypes = [vp, C.c_int, C.c_int, vp, i64, vp, vp, vp, vp]
         L.pengk_em.argtypes = [vp, C.c_int, i64, vp, f32, f32, C.c_int, vp, vp, vp, vp]
         L.pengk_em_device.argtypes = [vp, C.c_int, i64, vp, f32, f32, C.c_int, vp, vp, vp, vp]
+        L.pengk_motif_similarity.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp]
         L.pengk_comm_unique_id.argtypes = [vp]
         L.pengk_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
         L.pengk_comm_init_env.argtypes = [vp]

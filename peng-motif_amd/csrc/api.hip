@@ -115,6 +115,7 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_iupac_big) (void)hipFree(ctx->d_iupac_big);
   if (ctx->d_bg_partials) (void)hipFree(ctx->d_bg_partials);
   if (ctx->d_count_aux) (void)hipFree(ctx->d_count_aux);
+  if (ctx->d_sim) (void)hipFree(ctx->d_sim);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return PENGK_OK;
@@ -383,6 +384,35 @@ int pengk_pattern_stats(pengk_ctx* ctx, int W, int both, int k, int max_k, const
   return launch_stats(ctx, W, both ? 1 : 0, k, max_k, d_V, d_ltot, d_counts, d_bgprob, d_expected, d_logp, d_z);
 }
 
+int pengk_seed_candidates(pengk_ctx* ctx, int W, const float* d_z, const uint32_t* d_counts, float z_threshold,
+                          uint64_t count_threshold, uint32_t* h_ids, float* h_z, int64_t capacity, int64_t* n_out) {
+  if (!ctx || !d_z || !d_counts || !n_out || (capacity && (!h_ids || !h_z))) return fail(PENGK_ERR_ARG, "pengk_seed_candidates: NULL argument");
+  if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
+  if (capacity < 0 || capacity > (int64_t)1 << 28) return fail(PENGK_ERR_ARG, "pengk_seed_candidates: capacity out of range");
+  PENGK_ENTER(ctx);
+  const uint32_t cap = (uint32_t)capacity;
+  const uint32_t cthr = count_threshold > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)count_threshold;
+  const size_t need = 256 + (size_t)cap * 8;
+  int rc = ensure_scratch(ctx, &ctx->d_misc, &ctx->misc_bytes, need);
+  if (rc) return rc;
+  uint32_t* d_n = (uint32_t*)ctx->d_misc;
+  uint32_t* d_ids = (uint32_t*)((char*)ctx->d_misc + 256);
+  float* d_zs = (float*)(d_ids + cap);
+  rc = launch_seed_candidates(ctx, W, d_z, d_counts, z_threshold, cthr, cap, d_n, d_ids, d_zs);
+  if (rc) return rc;
+  uint32_t n = 0;
+  PENGK_HIP(hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  *n_out = n;
+  const uint32_t got = n < cap ? n : cap;  // n > capacity: the caller retries with room for n
+  if (got) {
+    PENGK_HIP(hipMemcpyAsync(h_ids, d_ids, (size_t)got * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PENGK_HIP(hipMemcpyAsync(h_z, d_zs, (size_t)got * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return PENGK_OK;
+}
+
 int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids, int64_t n, const uint32_t* d_counts,
                           const float* d_bgp, const float* d_expected, pengk_iupac_stats* h_out) {
   if (!ctx || (n && (!h_ids || !h_out)) || !d_counts || !d_bgp || !d_expected)
@@ -392,6 +422,34 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids
   if (n < 0) return fail(PENGK_ERR_ARG, "negative pattern count");
   if (n == 0) return PENGK_OK;
   return launch_iupac(ctx, W, both ? 1 : 0, h_ids, n, d_counts, d_bgp, d_expected, h_out);
+}
+
+int pengk_motif_similarity(pengk_ctx* ctx, int n, const float* h_pwm, const float* h_comp, const int32_t* h_len,
+                           const uint64_t* h_sites, int both, const float* h_bg, int first_new, float* h_out) {
+  if (!ctx || !h_pwm || !h_comp || !h_len || !h_sites || !h_bg || !h_out) return fail(PENGK_ERR_ARG, "pengk_motif_similarity: NULL argument");
+  if (n < 0 || first_new < 0 || first_new > n) return fail(PENGK_ERR_ARG, "pengk_motif_similarity: n = %d, first_new = %d", n, first_new);
+  for (int i = 0; i < n; ++i)
+    if (h_len[i] < 1 || h_len[i] > PENGK_MAX_MOTIF_LEN)
+      return fail(PENGK_ERR_UNSUPPORTED, "pengk_motif_similarity: motif %d has %d columns (1..%d)", i, h_len[i], PENGK_MAX_MOTIF_LEN);
+  long long pairs = 0;
+  for (int j = first_new; j < n; ++j) pairs += j;
+  if (pairs == 0) return PENGK_OK;
+  PENGK_ENTER(ctx);
+  const size_t pw = (size_t)n * PENGK_MAX_MOTIF_LEN * 4 * sizeof(float);
+  const size_t o_len = 2 * pw, o_sites = (o_len + (size_t)n * 4 + 255) & ~(size_t)255, o_out = (o_sites + (size_t)n * 8 + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, &ctx->d_sim, &ctx->sim_bytes, o_out + (size_t)pairs * sizeof(float));
+  if (rc) return rc;
+  char* base = (char*)ctx->d_sim;
+  PENGK_HIP(hipMemcpyAsync(base, h_pwm, pw, hipMemcpyHostToDevice, ctx->stream));
+  PENGK_HIP(hipMemcpyAsync(base + pw, h_comp, pw, hipMemcpyHostToDevice, ctx->stream));
+  PENGK_HIP(hipMemcpyAsync(base + o_len, h_len, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  PENGK_HIP(hipMemcpyAsync(base + o_sites, h_sites, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_similarity(ctx, n, (const float*)base, (const float*)(base + pw), (const int32_t*)(base + o_len),
+                         (const uint64_t*)(base + o_sites), both ? 1 : 0, h_bg, first_new, (float*)(base + o_out));
+  if (rc) return rc;
+  PENGK_HIP(hipMemcpyAsync(h_out, base + o_out, (size_t)pairs * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  return PENGK_OK;
 }
 
 int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,

@@ -42,6 +42,8 @@ struct pengk_ctx {
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms
   int scatter_blocks_per_cu = 0; // tuning hook: workgroups per CU of the partitioned scan (0 = default)
+  void* d_sim = nullptr;         // motif similarity grid: PWMs | complements | lengths | sites | scores
+  size_t sim_bytes = 0;
   void* comm = nullptr;          // RCCL communicator (comm.hip); NULL = single rank
   int comm_rank = 0, comm_world = 1;
 };
@@ -95,6 +97,10 @@ int launch_synth(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t n_seq, u
                  uint64_t* d_words, uint64_t* d_items);
 int launch_stats(pengk_ctx* ctx, int W, int both, int k, int max_k, const float* d_V, const uint64_t* d_ltot,
                  const uint32_t* d_counts, float* d_bgprob, float* d_expected, float* d_logp, float* d_z);
+int launch_seed_candidates(pengk_ctx* ctx, int W, const float* d_z, const uint32_t* d_counts, float z_threshold,
+                           uint32_t count_threshold, uint32_t cap, uint32_t* d_n, uint32_t* d_ids, float* d_zs);
+int launch_similarity(pengk_ctx* ctx, int n, const float* d_pwm, const float* d_comp, const int32_t* d_len,
+                      const uint64_t* d_sites, int both, const float* h_bg, int first_new, float* d_out);
 int launch_iupac(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids, int64_t n, const uint32_t* d_counts,
                  const float* d_bgp, const float* d_expected, pengk_iupac_stats* h_out);
 int launch_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,

@@ -106,7 +106,46 @@ int launch_w(pengk_ctx* ctx, int both, int k, int max_k, const float* d_V, const
   return PENGK_OK;
 }
 
+// ---- seed candidates (BasePattern::select_base_patterns, src/base_pattern.cpp:443-515, first half) -----------------
+// The reference sorts ALL 4^W ids by z and walks the ranking down to the threshold; only ids with z >= threshold and
+// count >= threshold can become seeds.  This kernel compacts exactly those (id, z) pairs: wave ballot, one atomic per
+// wave.  Order of the list is arbitrary; the caller sorts the few thousand survivors.
+__global__ __launch_bounds__(256) void seed_candidates_kernel(const float* __restrict__ z, const uint32_t* __restrict__ counts,
+                                                              uint32_t np, float z_threshold, uint32_t count_threshold,
+                                                              uint32_t cap, uint32_t* __restrict__ n_out,
+                                                              uint32_t* __restrict__ ids, float* __restrict__ zs) {
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < np; base += gridDim.x * blockDim.x) {
+    const uint32_t x = base + lane;
+    const float zx = x < np ? z[x] : 0.0f;
+    const bool keep = x < np && !(zx < z_threshold) && counts[x] >= count_threshold;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+    if (m == 0) continue;
+    uint32_t first = 0;
+    if (lane == 0) first = atomicAdd(n_out, (uint32_t)__builtin_popcountll(m));
+    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+    if (keep) {
+      const uint32_t at = first + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (at < cap) {
+        ids[at] = x;
+        zs[at] = zx;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int launch_seed_candidates(pengk_ctx* ctx, int W, const float* d_z, const uint32_t* d_counts, float z_threshold,
+                           uint32_t count_threshold, uint32_t cap, uint32_t* d_n, uint32_t* d_ids, float* d_zs) {
+  const uint32_t np = 1u << (2 * W);
+  PENGK_HIP(hipMemsetAsync(d_n, 0, sizeof(uint32_t), ctx->stream));
+  const uint32_t need = (np + 255) / 256, lim = (uint32_t)ctx->num_cu * 8u;
+  hipLaunchKernelGGL(seed_candidates_kernel, dim3(need < lim ? need : lim), dim3(256), 0, ctx->stream, d_z, d_counts, np,
+                     z_threshold, count_threshold, cap, d_n, d_ids, d_zs);
+  PENGK_HIP(hipGetLastError());
+  return PENGK_OK;
+}
 
 int launch_stats(pengk_ctx* ctx, int W, int both, int k, int max_k, const float* d_V, const uint64_t* d_ltot,
                  const uint32_t* d_counts, float* d_bgprob, float* d_expected, float* d_logp, float* d_z) {

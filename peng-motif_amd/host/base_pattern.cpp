@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <string>
 #include <iomanip>
 #include <iostream>
 
@@ -194,15 +196,46 @@ std::vector<size_t> BasePattern::select_base_patterns(const float zscore_thresho
                                                       bool single_stranded, bool filter_neighbors) {
   std::vector<size_t> selected;
   std::vector<char> seen(number_patterns, 0);
-  // the ranking std::sort(order, sort_indices(pattern_zscore)) would leave (:458), down to the threshold only
   std::vector<ranked_prefix::Entry> order;
-  const float* pattern_zscore = host_zscore();
-  const size_t* pattern_counter = host_counts();
-  const size_t n_ranked = ranked_prefix::rank(pattern_zscore, number_patterns, zscore_threshold, order);
+  size_t n_ranked = 0;
+  static const bool on_device = [] {
+    const char* e = std::getenv("PENGK_SEED_SELECT");
+    return e && std::string(e) == "device";
+  }();
+  if (on_device) {
+    // Opt-in fast mode: the candidates (z >= threshold, count >= threshold) are compacted on the
+    // device and ranked here by (z descending, id ascending) -- no 4^W tables cross the link, no 4^W-entry ranking.
+    // DOCUMENTED DIFFERENCE: exact z ties (every reverse-complement pair under both strands) are ordered by id, where
+    // the reference leaves them in the order of its non-stable std::sort; the seed set is the same up to the strand
+    // a pair is named on (tests/test_gpu_cli.py).
+    std::vector<uint32_t> ids(1 << 16);
+    std::vector<float> zs(ids.size());
+    int64_t n = 0;
+    for (;;) {
+      check(pengk_seed_candidates(context(), (int)pattern_length, d_z.get(), d_counts.get(), zscore_threshold, count_threshold,
+                                  ids.data(), zs.data(), (int64_t)ids.size(), &n),
+            "pengk_seed_candidates");
+      if ((size_t)n <= ids.size()) break;
+      ids.resize((size_t)n);
+      zs.resize((size_t)n);
+    }
+    order.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) order[i] = ranked_prefix::Entry{zs[i], ids[i]};
+    std::sort(order.begin(), order.end(), [](const ranked_prefix::Entry& a, const ranked_prefix::Entry& b) {
+      return a.z > b.z || (a.z == b.z && a.id < b.id);
+    });
+    n_ranked = order.size();
+  }
+  // default: the ranking std::sort(order, sort_indices(pattern_zscore)) would leave (:458), down to the threshold only
+  const float* pattern_zscore = on_device ? nullptr : host_zscore();
+  const size_t* pattern_counter = on_device ? nullptr : host_counts();
+  if (!on_device) n_ranked = ranked_prefix::rank(pattern_zscore, number_patterns, zscore_threshold, order);
   for (size_t r = 0; r < n_ranked; ++r) {
     const size_t x = order[r].id;
-    if (pattern_zscore[x] < zscore_threshold) break;
-    if (pattern_counter[x] < count_threshold) continue;
+    if (!on_device) {
+      if (pattern_zscore[x] < zscore_threshold) break;
+      if (pattern_counter[x] < count_threshold) continue;
+    }
     if (seen[x] || (!single_stranded && seen[getFastRevCompId(x)])) continue;
     selected.push_back(x);
     seen[x] = 1;

@@ -2,6 +2,7 @@
 #include "peng.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -131,9 +132,21 @@ void Peng::filter_redundancy(const float merge_bit_factor_threshold, std::vector
 }
 
 // ---- greedy pairwise merging (src/peng.cpp:237-313) ----------------------------------------------------------
-// The reference recomputes the similarity of EVERY pair after each merge (O(merges * n^2 * W * shifts)); a pair's
-// score depends on the two motifs only, so scores are kept per pair of motif serial numbers and only the pairs of the
-// newly merged motif are evaluated in later rounds.  Scan order and the strict `>` tie-break are the reference's.
+// The reference recomputes the similarity of EVERY pair after each merge (O(merges * n^2 * W * shifts) Jensen-Shannon
+// terms, three log2 each).  Two things are kept instead:
+//  * exact scores (the reference's arithmetic, IUPACPattern::calculate_S) per pair of motif serial numbers -- a pair's
+//    score depends on the two motifs only;
+//  * for sets of MERGE_GRID_MIN motifs and more, the device's similarity grid (pengk_motif_similarity: the same
+//    scores in fp64, within ~1e-4 of the reference's float-rounded sums): a round needs the MAXIMUM over all pairs, so
+//    only pairs whose device score lies within MERGE_MARGIN of the device maximum can be it, and only those are
+//    evaluated exactly.  After a merge the new motif's column is the only part of the grid that is computed.
+// Scan order and the strict `>` tie-break over the exactly evaluated pairs are the reference's, and every pair that
+// could win is among them: decisions, printed motifs and scores are unchanged.
+namespace {
+constexpr size_t MERGE_GRID_MIN = 96;
+constexpr float MERGE_MARGIN = 2e-3f;  // >> 3 sums x 56 terms x half a float ulp at |s| <= 32 (2e-4)
+}  // namespace
+
 void Peng::merge_iupac_patterns(const size_t pattern_length, const float threshold_factor, BackgroundModel*,
                                 std::vector<IUPACPattern*>& pats, size_t max_merged_length) {
   struct Similarity {
@@ -141,31 +154,98 @@ void Peng::merge_iupac_patterns(const size_t pattern_length, const float thresho
     int shift;
     bool comp;
   };
-  std::map<std::pair<size_t, size_t>, Similarity> known;  // (serial of pats[i], serial of pats[j]), i < j
+  std::map<std::pair<size_t, size_t>, Similarity> known;  // exact, by (serial of pats[i], serial of pats[j]), i < j
   std::vector<size_t> serial(pats.size());
   size_t next_serial = 0;
   for (size_t& x : serial) x = next_serial++;
+  auto exact = [&](size_t i, size_t j) -> const Similarity& {
+    const auto key = std::make_pair(serial[i], serial[j]);
+    auto it = known.find(key);
+    if (it == known.end()) {
+      auto res = IUPACPattern::calculate_S(pats[i], pats[j], strand, bg_model->getV()[0]);
+      it = known.emplace(key, Similarity{std::get<0>(res), std::get<1>(res), std::get<2>(res)}).first;
+    }
+    return it->second;
+  };
+
+  // ---- device grid over the eligible motifs (log p <= -5, :253,:256), keyed by serial numbers ---------------------
+  size_t n_eligible = 0;
+  for (IUPACPattern* p : pats) n_eligible += !(p->getLogPval() > -5);
+  const char* force = std::getenv("PENGK_MERGE_GRID");  // "host": exact scores only (tests compare the two paths)
+  bool grid = n_eligible >= MERGE_GRID_MIN && !(force && std::string(force) == "host");
+  for (IUPACPattern* p : pats) grid = grid && p->get_pattern_length() <= (size_t)PENGK_MAX_MOTIF_LEN;
+  const size_t S = 2 * pats.size() + 2;  // serial numbers never exceed n + merges <= 2 n
+  std::vector<float> approx;
+  const float none = std::numeric_limits<float>::quiet_NaN();
+  auto grid_update = [&](size_t first_new_pos) {
+    // every pair (i, j), i < j, with pats[j] at position >= first_new_pos, among the eligible motifs
+    std::vector<size_t> el;
+    for (size_t i = 0; i < pats.size(); ++i)
+      if (!(pats[i]->getLogPval() > -5)) el.push_back(i);
+    size_t first_new = el.size();
+    for (size_t k = 0; k < el.size(); ++k)
+      if (el[k] >= first_new_pos) {
+        first_new = k;
+        break;
+      }
+    const int n = (int)el.size();
+    size_t pairs = 0;
+    for (size_t j = first_new; j < el.size(); ++j) pairs += j;
+    if (!pairs) return;
+    const size_t cell = (size_t)PENGK_MAX_MOTIF_LEN * 4;
+    std::vector<float> pw(n * cell, 0.0f), cp(n * cell, 0.0f), out(pairs);
+    std::vector<int32_t> len(n);
+    std::vector<uint64_t> sites(n);
+    for (int k = 0; k < n; ++k) {
+      IUPACPattern* p = pats[el[k]];
+      len[k] = (int32_t)p->get_pattern_length();
+      sites[k] = (uint64_t)p->get_sites();
+      for (int c = 0; c < len[k]; ++c)
+        for (int a = 0; a < 4; ++a) {
+          pw[k * cell + c * 4 + a] = p->get_pwm()[c][a];
+          cp[k * cell + c * 4 + a] = p->get_comp_pwm()[c][a];
+        }
+    }
+    pengk_host::check(pengk_motif_similarity(pengk_host::context(), n, pw.data(), cp.data(), len.data(), sites.data(),
+                                             strand == Strand::BOTH_STRANDS, bg_model->getV()[0], (int)first_new, out.data()),
+                      "pengk_motif_similarity");
+    size_t q = 0;
+    for (size_t j = first_new; j < el.size(); ++j)
+      for (size_t i = 0; i < j; ++i) approx[serial[el[i]] * S + serial[el[j]]] = out[q++];
+  };
+  if (grid) {
+    approx.assign(S * S, none);
+    grid_update(0);
+  }
+
   for (;;) {
     float best_score = -std::numeric_limits<float>::infinity();
     size_t bi = 0, bj = 0;
     int best_shift = 0;
     bool best_comp = false;
+    float floor = -std::numeric_limits<float>::infinity();  // device scores below it cannot be the maximum
+    if (grid) {
+      float amax = -std::numeric_limits<float>::infinity();
+      for (size_t i = 0; i < pats.size(); ++i) {
+        if (pats[i]->getLogPval() > -5) continue;
+        const float* row = &approx[serial[i] * S];
+        for (size_t j = i + 1; j < pats.size(); ++j)
+          if (!(pats[j]->getLogPval() > -5) && row[serial[j]] > amax) amax = row[serial[j]];
+      }
+      floor = amax - MERGE_MARGIN;
+    }
     for (size_t i = 0; i < pats.size(); ++i) {
       if (pats[i]->getLogPval() > -5) continue;
       for (size_t j = i + 1; j < pats.size(); ++j) {
         if (pats[j]->getLogPval() > -5) continue;
-        const auto key = std::make_pair(serial[i], serial[j]);
-        auto it = known.find(key);
-        if (it == known.end()) {
-          auto res = IUPACPattern::calculate_S(pats[i], pats[j], strand, bg_model->getV()[0]);
-          it = known.emplace(key, Similarity{std::get<0>(res), std::get<1>(res), std::get<2>(res)}).first;
-        }
-        if (it->second.score > best_score) {
-          best_score = it->second.score;
+        if (grid && approx[serial[i] * S + serial[j]] < floor) continue;
+        const Similarity& sim = exact(i, j);
+        if (sim.score > best_score) {
+          best_score = sim.score;
           bi = i;
           bj = j;
-          best_shift = it->second.shift;
-          best_comp = it->second.comp;
+          best_shift = sim.shift;
+          best_comp = sim.comp;
         }
       }
     }
@@ -193,6 +273,10 @@ void Peng::merge_iupac_patterns(const size_t pattern_length, const float thresho
     serial.erase(serial.begin() + bj);
     serial.erase(serial.begin() + bi);
     serial.push_back(next_serial++);
+    if (grid) {
+      if (merged->get_pattern_length() > (size_t)PENGK_MAX_MOTIF_LEN) grid = false;  // (max_merged_length > 64: exact scores only)
+      else grid_update(pats.size() - 1);
+    }
   }
 }
 

@@ -161,3 +161,43 @@ def test_cli_exit_codes(tmp_path):
     bad = tmp_path / "bad.fa"
     bad.write_text(">a\nAC GT\n")
     assert subprocess.run([CLI, str(bad)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 1
+
+
+def test_device_seed_selection_is_the_reference_set_up_to_strand(tmp_path):
+    """PENGK_SEED_SELECT=device (opt-in): the printed seed table holds the same k-mers as the default
+    (reference-ranked) run up to the strand a reverse-complement pair is named on, with the same counts and z-scores."""
+    comp = str.maketrans("ACGT", "TGCA")
+
+    def seed_table(env_extra):
+        r = subprocess.run([CLI, os.path.join(ROOT, "tests", "golden", "MafK.fasta"), "-w", "10", "--no-em", "--no-merging"], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=dict(os.environ, **env_extra), timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        lines = r.stdout.decode().split("\n")
+        start = next(i for i, l in enumerate(lines) if "pattern" in l and "zscore" in l) + 2
+        rows = []
+        for l in lines[start:]:
+            f = l.split()
+            if len(f) != 4:
+                break
+            rows.append((min(f[0], f[0].translate(comp)[::-1]), f[1], f[3]))
+        return rows
+
+    ref = seed_table({})
+    dev = seed_table({"PENGK_SEED_SELECT": "device"})
+    assert len(ref) > 100 and sorted(ref) == sorted(dev)
+
+
+def test_merging_through_the_device_similarity_grid_prints_what_the_exact_path_prints(tmp_path):
+    """Many motifs (z threshold 4, up to 1000 optimised patterns: ~220 PWMs reach the merge loop): the device similarity
+    grid picks the candidate pairs, the reference's arithmetic decides among them -- stdout (every `merge:` line), MEME
+    and JSON equal the exact-scores-only path (PENGK_MERGE_GRID=host) byte for byte."""
+    outs = []
+    for tag, extra in (("grid", {}), ("host", {"PENGK_MERGE_GRID": "host"})):
+        meme, js = tmp_path / (tag + ".meme"), tmp_path / (tag + ".json")
+        r = subprocess.run([CLI, os.path.join(ROOT, "tests", "golden", "MafK.fasta"), "-w", "10", "-t", "4", "--max-optimized-patterns",
+                            "1000", "--minimum-processed-patterns", "1000", "-o", str(meme), "-j", str(js)], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=dict(os.environ, **extra), timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append((r.stdout, meme.read_bytes(), js.read_bytes()))
+    assert outs[0][0].count(b"\nmerge: ") >= 20 and outs[0][0].count(b"\nem: ") >= 150
+    assert outs[0] == outs[1]

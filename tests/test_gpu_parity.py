@@ -739,3 +739,131 @@ def test_em_serial_mode_many_pwms_in_batches(ctx, golden_dir):
         p0, it0, ch0 = po.em(W, r["counts"], r["bgp"][K], pwms[i], 1e4, 0.0, 2, mode=0, final_norm=False)
         assert bits_equal(pw[i], p0), i
         assert np.float32(change[i]).view(np.uint32) == np.float32(ch0).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", ["mafk_w10_both", "mafk_w10_plus", "mafk100_w8_both"])
+def test_seed_candidates_on_device(ctx, golden_dir, name):
+    """pengk_seed_candidates compacts exactly the ids the reference's walk can reach (z >= threshold, count >= threshold,
+    src/base_pattern.cpp:463-466); ranked by (z descending, id ascending) and walked with the reference's seen /
+    neighbour logic they give the golden seed list up to the strand a reverse-complement pair is named on."""
+    import ctypes as C
+    r = cpu_pipeline(golden_dir, name)
+    W, both = r["W"], r["both"]
+    d = gpu_tables(ctx, r)
+    zthr, cthr = 10.0, 3
+    cap = 1 << 16
+    ids = np.zeros(cap, np.uint32)
+    zs = np.zeros(cap, np.float32)
+    n = C.c_int64()
+    pk._check(pk.lib().pengk_seed_candidates(ctx.h, W, pk._ptr(d["z"]), pk._ptr(d["counts"]), zthr, cthr, ids.ctypes.data,
+                                             zs.ctypes.data, cap, C.byref(n)))
+    want = np.nonzero((r["z"] >= zthr) & (r["counts"] >= cthr))[0]
+    got = np.sort(ids[: n.value])
+    assert n.value == len(want) and np.array_equal(got, want.astype(np.uint32))
+    assert np.array_equal(zs[: n.value], r["z"][ids[: n.value]])
+    # a too small buffer reports the full count
+    n2 = C.c_int64()
+    pk._check(pk.lib().pengk_seed_candidates(ctx.h, W, pk._ptr(d["z"]), pk._ptr(d["counts"]), zthr, cthr, ids.ctypes.data,
+                                             zs.ctypes.data, 4, C.byref(n2)))
+    assert n2.value == n.value
+    if not both:
+        # single strand: exact z ties between DIFFERENT k-mers that are Hamming neighbours of each other are broken by
+        # the reference's non-stable sort; (z desc, id asc) may keep the other one (the documented difference of the
+        # opt-in mode).  The candidate set above is what is exact.
+        return
+    # the walk over (z desc, id asc): same seeds as the reference's ranking up to strand
+    order = np.lexsort((ids[: n.value], -zs[: n.value].astype(np.float64)))
+    seen = np.zeros(4 ** W, bool)
+    sel = []
+    for x in ids[: n.value][order].tolist():
+        if seen[x] or (both and seen[po.revcomp(x, W)]):
+            continue
+        sel.append(x)
+        seen[x] = True
+        for p_ in range(W):
+            for c in range(4):
+                seen[(x & ~(3 << (2 * p_))) | (c << (2 * p_))] = True
+    canon = lambda x: min(x, po.revcomp(x, W)) if both else x  # noqa: E731
+    ref_seeds = po.select(W, r["z"], r["counts"], zthr, cthr, not both, True)
+    assert sorted(canon(x) for x in sel) == sorted(canon(int(x)) for x in ref_seeds)
+
+
+def _exact_S(p1, c1, s1, p2, c2, s2, both, bg):
+    """IUPACPattern::calculate_S restated with its float32 running sums (src/iupac_pattern.cpp:538-615)."""
+    f32, f64 = np.float32, np.float64
+    eps = f32(1e-4)
+
+    def term(x, y):
+        mean = f32(f32(f32(x + y) + f32(2) * eps) / f32(2))
+        return (f64(f32(x + eps)) * np.log2(f64(f32(x + eps))) + f64(f32(y + eps)) * np.log2(f64(f32(y + eps)))
+                - f64(f32(f32(2) * mean)) * np.log2(f64(mean)))
+
+    def d(a, b, oa, ob, n):
+        acc = f32(0)
+        for i in range(n):
+            for k in range(4):
+                acc = f32(f64(acc) + term(a[oa + i][k], b[ob + i][k]))
+        return acc
+
+    def dbg(a, oa, n):
+        acc = f32(0)
+        for i in range(n):
+            for k in range(4):
+                acc = f32(f64(acc) + term(a[oa + i][k], bg[k]))
+        return acc
+
+    big, small = (p1, c1, s1), (p2, c2, s2)
+    if len(p1) < len(p2):
+        big, small = small, big
+    lb, ls = len(big[0]), len(small[0])
+    best = -np.inf
+    for orient in range(2 if both else 1):
+        pb, ps = big[0], small[0]
+        if orient == 1:
+            if big[2] < small[2]:
+                pb = big[1]
+            else:
+                ps = small[1]
+        for shift in range(6 - ls, lb - 6 + 1):
+            off_s, off_b = -min(shift, 0), max(shift, 0)
+            ov = min(lb - off_b, ls - off_s)
+            sc = f32(0.5 * f64(f32(dbg(pb, off_b, ov) + dbg(ps, off_s, ov))) - f64(d(pb, ps, off_b, off_s, ov)))
+            if sc > best:
+                best = sc
+    return best
+
+
+@pytest.mark.parametrize("both", [True, False])
+def test_motif_similarity_grid_within_margin_of_the_reference_arithmetic(ctx, both):
+    """pengk_motif_similarity (fp64 on the device) against calculate_S restated with the reference's float32 running
+    sums, on motifs of mixed lengths (merged motifs are longer than W): every pair within 5e-4 -- a quarter of the
+    margin the host mirror uses to pick the pairs it evaluates exactly -- for the whole triangle and for the
+    one-new-motif column that follows a merge."""
+    rng = np.random.default_rng(11)
+    n, ML = 40, 64
+    lens = rng.integers(6, 15, size=n).astype(np.int32)
+    lens[:8] = 10
+    pw = np.zeros((n, ML, 4), np.float32)
+    cp = np.zeros((n, ML, 4), np.float32)
+    for i in range(n):
+        m = rng.dirichlet(np.full(4, 0.3), size=lens[i]).astype(np.float32)
+        m = np.maximum(m, np.float32(1e-8))
+        pw[i, :lens[i]] = m
+        cp[i, :lens[i]] = m[::-1, ::-1]
+    sites = rng.integers(10, 5000, size=n).astype(np.uint64)
+    sites[3] = sites[4]  # equal site counts: the SMALL motif is complemented
+    bg = np.array([0.27, 0.23, 0.21, 0.29], np.float32)
+    out = np.zeros(n * (n - 1) // 2, np.float32)
+    pk._check(pk.lib().pengk_motif_similarity(ctx.h, n, pw.ctypes.data, cp.ctypes.data, lens.ctypes.data, sites.ctypes.data,
+                                              int(both), bg.ctypes.data, 0, out.ctypes.data))
+    q, worst = 0, 0.0
+    for j in range(n):
+        for i in range(j):
+            want = _exact_S(pw[i, :lens[i]], cp[i, :lens[i]], sites[i], pw[j, :lens[j]], cp[j, :lens[j]], sites[j], both, bg)
+            worst = max(worst, abs(float(out[q]) - float(want)))
+            q += 1
+    assert worst <= 5e-4, worst
+    col = np.zeros(n - 1, np.float32)
+    pk._check(pk.lib().pengk_motif_similarity(ctx.h, n, pw.ctypes.data, cp.ctypes.data, lens.ctypes.data, sites.ctypes.data,
+                                              int(both), bg.ctypes.data, n - 1, col.ctypes.data))
+    assert np.array_equal(col, out[-(n - 1):])
