@@ -459,7 +459,6 @@ struct ScatterEmit {
   static constexpr int NB = 1 << NBITS;
   static_assert(GROUP == 64, "a group is one 2-byte store per lane");
   static_assert(RING_CAP == 128, "byte 0 of the counter addresses the ring");
-  typedef __attribute__((address_space(1))) uint16_t global_u16;
   uint16_t* __restrict__ keys;
   uint32_t slice_cap;  // entries per (wave, bucket) slice, multiple of 64; NB * slice_cap < 2^32
   uint32_t* __restrict__ slice_fill;  // [n_waves][NB] entries written (multiple of 64)
@@ -476,32 +475,46 @@ struct ScatterEmit {
       w[i] = (i % (uint32_t)(sizeof(ScatterRow) / 4u)) == (uint32_t)(RING_CAP / 2) ? 0u : 0xFFFFFFFFu;
   }
 
-  // A completed group (64 ring entries from slot g0, a multiple of 64) goes to slice entries [g0, g0 + 64) as ONE
-  // 128-byte line, one 2-byte store per lane (PARTIAL: entries >= nvalid become KEY_INVALID).  b, g0 and nvalid
-  // are wave-uniform.
-  template <bool PARTIAL>
-  __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
-    typedef const volatile __attribute__((address_space(3))) uint16_t lds_u16;  // a generic pointer would become a flat load
-    lds_u16* ring16 = (lds_u16*)&scatter_lds<NBITS, WPW>().row[wave][b].ring[0];
-    uint32_t v = (uint32_t)ring16[(g0 & (uint32_t)(RING_CAP - 1)) + lane];
-    if (PARTIAL && lane >= nvalid) v = KEY_INVALID;
-    if (g0 + (uint32_t)GROUP <= slice_cap) {  // wave-uniform
-      // explicit global address space (a flat store would stall LDS waits); scalar base + lane * 2
-      global_u16* dst = (global_u16*)(keys + ((size_t)wave_global * NB * slice_cap + (size_t)(b * slice_cap + g0)));
-      __builtin_nontemporal_store((uint16_t)v, &dst[lane]);  // written once, read once by pass B
-    } else if (v != KEY_INVALID) {  // slice full: count these windows directly (rare; skewed inputs)
-      __hip_atomic_fetch_add(&hist[KS::join(b, v, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+  typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+  typedef __attribute__((address_space(1))) uint16_t global_u16_t;
 
-  __device__ __forceinline__ void flush_triggered(unsigned long long trig, uint32_t b, uint32_t s4) {
-    while (trig) {  // wave-uniform: a ring just completed a group of 64 (on average one per call)
-      const int src = __builtin_ctzll(trig);
-      trig &= trig - 1;
-      const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
-      const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)s4, src) >> 2;
-      __builtin_amdgcn_wave_barrier();
-      flush_group<false>(fb, fs - (uint32_t)(GROUP - 1), (uint32_t)GROUP);
+  // A completed group (64 ring entries from slot g0, a multiple of 64) goes to slice entries [g0, g0 + 64) as ONE
+  // 128-byte line, one 2-byte load and store per lane.  Everything wave-uniform about a group -- where it starts in
+  // the ring, where it goes in the wave's key region, whether the slice still has room -- is computed by the lane whose
+  // key completed it, with a handful of vector instructions that all lanes run side by side; the loop then needs two
+  // v_readlane per group and no scalar multiply / shift / mask chain (13 instruction issues per group instead of 30;
+  // the flush was half of what this kernel issues).
+  __device__ __forceinline__ void flush_triggered(unsigned long long trig, uint32_t row, uint32_t b, uint32_t s4) {
+    // (an empty asm: the compiler must not fold the caller's wave-uniform "some key completed a group" branch into the
+    // masks below -- that turns one scalar branch per key into five scalar instructions)
+    asm volatile("");
+    const uint32_t g4 = s4 - 4u * (uint32_t)(GROUP - 1);        // 4 x first slot of the group (in trigger lanes)
+    const uint32_t src = row + ((g4 >> 1) & (uint32_t)RING_CAP);  // ring byte offset 0 or 128
+    const uint32_t dst = b * (2u * slice_cap) + (g4 >> 1);        // byte offset in the wave's region; NB * cap < 2^31
+    const unsigned long long fits = __builtin_amdgcn_ballot_w64(g4 + 4u * GROUP <= 4u * slice_cap);
+    unsigned long long todo = trig & fits;
+    unsigned long long over = trig & ~fits;
+    while (todo) {  // wave-uniform: on average one group per step
+      const int p = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const uint32_t s_src = (uint32_t)__builtin_amdgcn_readlane((int)src, p);
+      const uint32_t s_dst = (uint32_t)__builtin_amdgcn_readlane((int)dst, p);
+      // A plain LDS load (a volatile one makes the compiler drain lgkmcnt(0) in front of it).  The LDS executes a wave's
+      // operations in order, so it sees every ring write issued before it; ring writes through integer-formed addresses
+      // lie between two reads of a location, so it cannot be satisfied from an older copy.
+      uint32_t v = *(lds_u16_t*)(uintptr_t)(s_src + 2u * lane);
+      asm volatile("" : "+v"(v));  // consumed here on every path: no wait for it leaks into the next window's code
+      global_u16_t* out = (global_u16_t*)((char*)region + s_dst);
+      __builtin_nontemporal_store((uint16_t)v, &out[lane]);  // written once, read once by pass B
+    }
+    while (over) {  // slice full: count these windows directly (rare; skewed inputs)
+      const int p = __builtin_ctzll(over);
+      over &= over - 1;
+      const uint32_t s_src = (uint32_t)__builtin_amdgcn_readlane((int)src, p);
+      const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)b, p);
+      const uint32_t v = *(lds_u16_t*)(uintptr_t)(s_src + 2u * lane);
+      if (v != KEY_INVALID) __hip_atomic_fetch_add(&hist[KS::join(fb, v, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -512,13 +525,13 @@ struct ScatterEmit {
   __device__ __forceinline__ void bind() {
     rowbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&scatter_lds<NBITS, WPW>().row[wave][0];
     asm volatile("" : "+v"(rowbase));
+    region = keys + (size_t)wave_global * NB * slice_cap;
   }
-  typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-  typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+  uint16_t* region = nullptr;  // this wave's key region (wave-uniform): NB slices of slice_cap entries
 
-  // append one key per lane; returns 4 x slot
-  __device__ __forceinline__ uint32_t append(uint32_t b, uint32_t key) const {
-    const uint32_t row = b * (uint32_t)sizeof(ScatterRow) + rowbase;  // b < NB: one v_mad_u32_u24
+  // append one key per lane: the row of its bucket (returned through `row`) and 4 x its slot
+  __device__ __forceinline__ uint32_t append(uint32_t b, uint32_t key, uint32_t& row) const {
+    row = b * (uint32_t)sizeof(ScatterRow) + rowbase;  // b < NB: one v_mad_u32_u24
     const uint32_t s4 = __hip_atomic_fetch_add((lds_u32_t*)(uintptr_t)(row + 2u * RING_CAP), 4u, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
     *(lds_u16_t*)(uintptr_t)(row + ((s4 >> 1) & 0xFFu)) = (uint16_t)KS::payload(key);
@@ -528,31 +541,42 @@ struct ScatterEmit {
   // every lane appends; key may be INVALID_ID (or any value whose payload bits are all ones)
   __device__ __forceinline__ void full(uint32_t key) {
     const uint32_t b = KS::bucket(key);
-    const uint32_t s4 = append(b, key);
-    flush_triggered(__builtin_amdgcn_ballot_w64((s4 & 0xFFu) == 4u * (uint32_t)(GROUP - 1)), b, s4);
+    uint32_t row;
+    const uint32_t s4 = append(b, key, row);
+    const unsigned long long trig = __builtin_amdgcn_ballot_w64((s4 & 0xFFu) == 4u * (uint32_t)(GROUP - 1));
+    if (trig) flush_triggered(trig, row, b, s4);  // wave-uniform
   }
 
   // only the lanes with `active` append
   __device__ __forceinline__ void masked(uint32_t key, bool active) {
     const uint32_t b = KS::bucket(key);
-    uint32_t s4 = 0;
-    if (active) s4 = append(b, key);
-    flush_triggered(__builtin_amdgcn_ballot_w64(active && (s4 & 0xFFu) == 4u * (uint32_t)(GROUP - 1)), b, s4);
+    uint32_t s4 = 0, row = 0;
+    if (active) s4 = append(b, key, row);
+    const unsigned long long trig = __builtin_amdgcn_ballot_w64(active && (s4 & 0xFFu) == 4u * (uint32_t)(GROUP - 1));
+    if (trig) flush_triggered(trig, row, b, s4);
   }
 
-  // end of kernel: partial groups, then publish how much of each slice is filled
+  // end of kernel: lane b pads bucket b's last, partial group with KEY_INVALID -- appending the padding, so that the
+  // group is complete and leaves like every other -- and publishes how much of the slice is filled
   __device__ __forceinline__ void drain() {
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t b = 0; b < (uint32_t)NB; ++b) {
-      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS, WPW>().row[wave][b].fill4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 2;
-      const uint32_t r = f & (uint32_t)(GROUP - 1);
-      if (r) flush_group<true>(b, f & ~(uint32_t)(GROUP - 1), r);
-    }
+    uint32_t row = 0, s4_last = 0;
+    bool padded = false;
     if (lane < (uint32_t)NB) {
-      const uint32_t f = __hip_atomic_load(&scatter_lds<NBITS, WPW>().row[wave][lane].fill4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 2;
-      const uint32_t full = (f + (uint32_t)(GROUP - 1)) & ~(uint32_t)(GROUP - 1);
+      row = lane * (uint32_t)sizeof(ScatterRow) + rowbase;
+      const uint32_t c4 = __hip_atomic_load((lds_u32_t*)(uintptr_t)(row + 2u * RING_CAP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const uint32_t r = (c4 >> 2) & (uint32_t)(GROUP - 1);
+      if (r) {
+        for (uint32_t i = r; i < (uint32_t)GROUP; ++i) *(lds_u16_t*)(uintptr_t)(row + (((c4 >> 1) & 0xFFu) + 2u * (i - r))) = (uint16_t)KEY_INVALID;
+        s4_last = c4 + 4u * ((uint32_t)GROUP - r) - 4u;  // the slot value the completing key would have got
+        padded = true;
+      }
+      const uint32_t full = ((c4 >> 2) + (uint32_t)(GROUP - 1)) & ~(uint32_t)(GROUP - 1);
       slice_fill[(size_t)wave_global * NB + lane] = full < slice_cap ? full : slice_cap;
     }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long trig = __builtin_amdgcn_ballot_w64(padded);
+    if (trig) flush_triggered(trig, row, lane, s4_last);
   }
 };
 
@@ -1124,7 +1148,7 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   uint64_t cap64 = share + share / 2 + 512;  // 1.5x the uniform share: real genomes are not uniform
   if (ctx->key_cap_override) cap64 = ctx->key_cap_override;  // test hook: force slices to overflow
   cap64 = (cap64 + 63) / 64 * 64;
-  if (cap64 * NB >= (1ull << 32))  // entry offsets inside a wave's NB slices are 32-bit
+  if (cap64 * NB >= (1ull << 31))  // byte offsets inside a wave's NB slices are 32-bit
     return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count (slice of %llu keys)", (unsigned long long)cap64);
   const uint32_t slice_cap = (uint32_t)cap64;
   int rc = ensure_scratch(ctx, &ctx->d_keys, &ctx->keys_bytes, (size_t)NB * n_waves * slice_cap * sizeof(uint16_t));
@@ -1192,7 +1216,7 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   uint64_t cap2_64 = share2 + share2 / 2 + 512;
   if (ctx->key_cap_override) cap2_64 = ctx->key_cap_override;
   cap2_64 = (cap2_64 + 63) / 64 * 64;
-  if (cap1_64 * 32ull >= (1ull << 32) || cap2_64 * 16ull >= (1ull << 32)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
+  if (cap1_64 * 32ull >= (1ull << 32) || cap2_64 * 16ull >= (1ull << 31)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
   const uint32_t cap1 = (uint32_t)cap1_64, cap2 = (uint32_t)cap2_64;
   const size_t bytes1 = (size_t)n_waves1 * 32u * cap1 * sizeof(uint32_t);
   const size_t bytes2 = (size_t)n_waves2 * 16u * cap2 * sizeof(uint16_t);
