@@ -228,6 +228,9 @@ def main():
                 ctx.record(ev["em"][1])
 
         def barrier():
+            # drain this rank's streams first: the exchange runs on libpengk's communicator, the barrier on torch's, and two
+            # communicators must not have collectives in flight on one GPU at the same time
+            torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
