@@ -107,7 +107,10 @@ def main():
                  "--nproc-per-node equal to --gpus" % (args.gpus, world))
     dist = None
     backend = None
-    if world > 1:
+    # PENGK_BENCH_FORCE_COMM=1: take the N > 1 code path (process group, RCCL communicator, exchange, gathers) with
+    # whatever world size the launcher gave, also 1 -- the only way to run it on a one-GPU test box
+    multi = world > 1 or bool(os.environ.get("PENGK_BENCH_FORCE_COMM"))
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # PENGK_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
@@ -136,8 +139,8 @@ def main():
     ctx.set_option("em_fast", args.em_fast)
 
     import ctypes as C
-    rccl_ranks = 1
-    if world > 1 and backend == "nccl":
+    rccl_ranks = 0
+    if multi and backend == "nccl":
         # the exchange step runs in the C++ library (RCCL on the context's stream); torch.distributed only carries the
         # 128-byte communicator id to the ranks, the barriers around the timed region and the max over ranks
         box = [None]
@@ -160,7 +163,7 @@ def main():
         items = torch.empty(max(ni.value, 1), dtype=torch.int64, device=dev)
         ctx.synth(1, rank * nseq, nseq, L, W, 0, words, items)
         nwin = L - W + 1
-        if rccl_ranks > 1:
+        if rccl_ranks:
             pk._check(lib.pengk_comm_check_bin_bound(ctx.h))
         else:
             sharding.check_global_bin_bound(nseq * ((nwin + W - 1) // W), dist)
@@ -196,7 +199,7 @@ def main():
         acc = {k: 0.0 for k in ev}
 
         def exchange():
-            if rccl_ranks > 1:  # the ONE exchange step (C1)
+            if rccl_ranks:  # the ONE exchange step (C1)
                 pk._check(lib.pengk_allreduce_tables(ctx.h, W, counts.data_ptr(), scal[84:].data_ptr(), scal.data_ptr()))
             else:               # no-op at N = 1; gloo rehearsal otherwise
                 sharding.allreduce_tables(counts, scal, dist)
@@ -231,7 +234,7 @@ def main():
             # drain this rank's streams first: the exchange runs on libpengk's communicator, the barrier on torch's, and two
             # communicators must not have collectives in flight on one GPU at the same time
             torch.cuda.synchronize()
-            if world > 1:
+            if multi:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -276,7 +279,7 @@ def main():
             torch.cuda.synchronize()
             mine = {int(i): pwms[j].cpu().numpy().tobytes().hex() for j, i in enumerate(my_pwms)}
             allp = [mine]
-            if world > 1:
+            if multi:
                 allp = [None] * world
                 dist.all_gather_object(allp, mine)
             merged = {}
@@ -343,7 +346,7 @@ def main():
                 best = d_k if best is None else min(best, d_k)
             k4 = (len(ids), members, best)
 
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -371,8 +374,8 @@ def main():
                        % (nseq, L, W, "both" if both else "plus", P_total, args.em_iters),
                        "n_seq_per_gpu": nseq, "seq_len": L, "W": W, "strand": args.strand, "ltot_global": ltot,
                        "parallelism": "sequence shards x%d, one all-reduce of the 4^W counts" % world,
-                       "exchange": ("RCCL, %d ranks, pengk_allreduce_tables on the kernels' stream" % rccl_ranks) if rccl_ranks > 1
-                       else ("none (one rank)" if world == 1 else "gloo rehearsal through the host (not a measured configuration)"),
+                       "exchange": ("RCCL, %d rank(s), pengk_allreduce_tables on the kernels' stream" % rccl_ranks) if rccl_ranks
+                       else ("none (one rank)" if not multi else "gloo rehearsal through the host (not a measured configuration)"),
                        "em_mode": mode_name[args.em_fast]},
             "components": {
                 "count_gbp_per_s_per_gpu": round(nseq * L / (count_ms * 1e-3) / 1e9, 3) if count_ms else None,
@@ -435,7 +438,7 @@ def main():
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

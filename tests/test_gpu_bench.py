@@ -87,6 +87,22 @@ def test_two_ranks_through_the_hip_path_reproduce_one_rank_bit_for_bit():
     assert two["checks"] == one["checks"], (two["checks"], one["checks"])
 
 
+def test_one_rank_through_the_rccl_code_path_of_the_bench():
+    """The N > 1 path of bench.py -- nccl process group, communicator id over the store, pengk_comm_init, the bin-bound
+    collective, pengk_allreduce_tables inside every step, the gathers -- with the one rank a one-GPU box can hold
+    (PENGK_BENCH_FORCE_COMM=1): same tables as the plain run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    forced = _bench(["--gpus", "1", "--nseq", "200000"], env=dict(os.environ, PENGK_BENCH_FORCE_COMM="1"),
+                    launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port)])
+    plain = _bench(["--nseq", "200000"])
+    assert forced["config"]["exchange"].startswith("RCCL, 1 rank")
+    assert forced["checks"] == plain["checks"]
+
+
 def test_gpus_flag_must_match_the_launch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), timeout=300)
