@@ -109,16 +109,17 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
       // c*s / (1 + s/(prod/bg)) == c*s*prod / (prod + s*bg): one reciprocal (v_rcp_f32, 1 ulp) instead of three
       // IEEE divisions (33 of the 42 VALU instructions of a leaf); c*s and s*bg come precomputed.
       // Same limits: prod = 0 -> 0.
-#ifdef PENGK_EM_ABLATE_LOADS  // experiment: all table reads hit one cache line
-      x &= 15u;
-#endif
-      const float cs = __builtin_bit_cast(float, counts[x]);
-      const float sb = bg[x];
+      // 32-bit byte offset + uniform base: one address instruction per k-mer for both tables (indexing the two
+      // pointers with x costs five 64-bit address instructions per k-mer, a third of what this kernel issued)
+      const uint32_t off = x << 2;
+      const float cs = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(counts) + off);
+      const float sb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bg) + off);
 #pragma unroll
       for (int q = 0; q < P; ++q) w[q] = (double)(cs * prod[q] * __builtin_amdgcn_rcpf(sb + prod[q]));
     } else {
-      const float cs = (float)counts[x] * saturation;
-      const float b = bg[x];
+      const uint32_t off = x << 2;
+      const float cs = (float)*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(counts) + off) * saturation;
+      const float b = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bg) + off);
 #pragma unroll
       for (int q = 0; q < P; ++q) {
         const float odds = prod[q] / b;
