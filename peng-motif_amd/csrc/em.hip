@@ -156,6 +156,41 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
       double s1[P];
 #pragma unroll
       for (int q = 0; q < P; ++q) s1[q] = 0.0;
+      if constexpr (FAST) {
+        // throughput mode: the 16 weights of a block are summed by rows and columns in float32 (sums of 4: within
+        // 2e-7 of exact, far inside this mode's 1e-5) and enter the fp64 tree as 9 values instead of 32 fp64 additions
+        float wf[P][4][4];
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2) {
+          float p2[P];
+#pragma unroll
+          for (int q = 0; q < P; ++q) p2[q] = po[q] * s_pwm[q][(G::PB + OUT) * 4 + d2];
+#pragma unroll
+          for (int d3 = 0; d3 < 4; ++d3) {
+            const uint32_t off = (xo | ((uint32_t)d2 << (2 * (G::PB + OUT))) | ((uint32_t)d3 << (2 * (G::PB + OUT + 1)))) << 2;
+            const float cs = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(counts) + off);
+            const float sb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bg) + off);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+              const float p3 = p2[q] * s_pwm[q][(G::PB + OUT + 1) * 4 + d3];
+              wf[q][d2][d3] = cs * p3 * __builtin_amdgcn_rcpf(sb + p3);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          float tot = 0.0f;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const float row = (wf[q][d][0] + wf[q][d][1]) + (wf[q][d][2] + wf[q][d][3]);
+            const float col = (wf[q][0][d] + wf[q][1][d]) + (wf[q][2][d] + wf[q][3][d]);
+            acc[q][OUT][d] += (double)row;
+            acc[q][OUT + 1][d] += (double)col;
+            tot += row;
+          }
+          s1[q] = (double)tot;
+        }
+      } else
 #pragma unroll
       for (int d2 = 0; d2 < 4; ++d2) {
         float p2[P];
@@ -558,9 +593,9 @@ int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, flo
     const int64_t wg4 = n_pwm * EmGeo<W, 4>::NB;
     if (wg4 * 4 < (int64_t)ctx->num_cu * 4) return fast ? PENGK_EM_GEO(2, true, 1) : PENGK_EM_GEO(2, false, 1);
     if (wg4 < (int64_t)ctx->num_cu * 8) return fast ? PENGK_EM_GEO(3, true, 1) : PENGK_EM_GEO(3, false, 1);
-    // (P = 2, two PWMs per workgroup sharing every table read, was measured on the 1000-PWM batch: 4.51 ms against
-    // 4.53 ms -- with the reads served from one cache line the kernel takes 3.2 ms, but what they cost is latency,
-    // not bandwidth, and halving their number does not shorten it.)
+    // (Sharing table reads between PWMs does not pay: two PWMs per thread need 198 registers -- two waves per SIMD,
+    // 4.3 ms against 3.9 ms; two / four PWMs per workgroup as thread groups walking the same slice, so that L1 serves
+    // the second read, 4.2 / 4.9 ms; forcing five or more waves per SIMD spills (4.0 / 7.0 / 13 ms).)
   }
   return fast ? PENGK_EM_GEO(4, true, 1) : PENGK_EM_GEO(4, false, 1);
 #undef PENGK_EM_GEO
