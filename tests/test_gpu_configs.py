@@ -1,12 +1,14 @@
 """BASELINE.json configs[3] and configs[4] at their real sizes, through the C ABI.
 
 configs[3]  "Synthetic 100M x 200 bp, W=12, seqs sharded 8 x MI355X": ONE shard of 12.5M sequences on the one GPU of
-            the test box (the reference cannot run it: 2.5e9 positions wrap its 32-bit counters), checked
+            the test box (a shard is the most the reference's 32-bit position counters can take), checked
             through size-independent properties -- ltot, shard additivity (what the all-reduce relies on), the two
-            independent emitters (direct atomics vs two-level partition) bin for bin, fused background totals -- and,
-            at the largest size the compiled reference handles in the build container (2M sequences = 400 Mbp, the
-            head of shard 0), against sha256 checksums of the reference's own tables (tests/golden/synth_checksums.json,
-            exercised by test_gpu_parity.py::test_device_generated_input_against_reference_checksums).
+            independent emitters (direct atomics vs two-level partition) bin for bin, fused background totals.  The
+            compiled reference's own results for this input live in tests/golden/synth_checksums.json and are compared by
+            test_gpu_parity.py::test_device_generated_input_against_reference_checksums: every table for the 2M-sequence
+            head of shard 0 (400 Mbp), and count table / ltot / background counters for the WHOLE shard 3 (2.65e9
+            positions, just inside the reference's 32-bit counters; its background model overflows an int beyond 2^31
+            bases, so V and z are not compared there).
 configs[4]  "W=10 --strand PLUS, 1000 seed PWMs, EM-only stress" exactly as SURVEY.md 8(d) defines it: the PLUS count
             table of the 10M x 200 bp set, the 1000 highest-count k-mers (ties by ascending id) as seeds, initial PWM
             row 0.7 at the seed's base and 0.1 elsewhere, --em-threshold 0, 10 iterations = 1.05e10 evaluations.
