@@ -103,6 +103,18 @@ def test_one_rank_through_the_rccl_code_path_of_the_bench():
     assert forced["checks"] == plain["checks"]
 
 
+def test_bench_starts_its_own_launcher_for_gpus_n():
+    """`python bench.py --gpus 2` without a launcher starts torch.distributed.run itself (as a child process, before
+    anything touches the GPU) and relays the one JSON line (gloo rehearsal: two ranks on the box's one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PENGK_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--nseq", "100000",
+                        "--em-stress-pwms", "0", "--k4-patterns", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["ltot_global"] == 2 * 100000 * 191
+
+
 def test_gpus_flag_must_match_the_launch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), timeout=300)
