@@ -344,7 +344,7 @@ struct FoldGeo {
   static constexpr uint32_t QUADS = C;                             // 16-byte pieces per stage: 4 cells x C / 4
   static constexpr uint32_t LOADERS = 128;
   static constexpr uint32_t QPT = (QUADS + LOADERS - 1) / LOADERS;  // quads per loader thread and stage
-  static constexpr uint32_t ROW = C + 36;                          // floats per cell row in LDS: + 8 quads the adder may read past the
+  static constexpr uint32_t ROW = C + 68;                          // floats per cell row in LDS: + 16 quads the adder may read past the
                                                                    // end (never added), + 16 B (rows on different banks)
 };
 
@@ -411,9 +411,9 @@ __global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict_
       if (s + 1 < F::STAGES) deposit((s + 1) & 1u);  // fetched during the previous stage
       if (s + 2 < F::STAGES) fetch(s + 2);
     } else if (lane < 4u) {
-      // two register sets of 8 quads: the LDS reads of the next 32 terms are in flight while these 32 are added
+      // two register sets of 16 quads: the LDS reads of the next 64 terms are in flight while these 64 are added
       const f4* src = reinterpret_cast<const f4*>(&buf[s & 1u][lane][0]);
-      constexpr uint32_t NQ = F::C / 4u, G = NQ < 8u ? NQ : 8u;
+      constexpr uint32_t NQ = F::C / 4u, G = NQ < 16u ? NQ : 16u;
       static_assert(NQ % (2u * G) == 0u || NQ == G, "quads per stage");
       f4 va[G], vb[G];
       auto rd = [&](f4 (&v)[G], uint32_t i0) {
@@ -423,8 +423,9 @@ __global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict_
       auto add = [&](f4 (&v)[G]) {
         // all quads of the set are "used" here at once: ONE s_waitcnt in front of the 4 G additions instead of one per
         // quad (every instruction of the adding wave, waits included, costs the chain an issue turn)
-        if constexpr (G == 8)
-          asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+        if constexpr (G == 16)
+          asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
 #pragma unroll
         for (uint32_t k = 0; k < G; ++k) {
           acc += v[k].x;
