@@ -206,10 +206,11 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  * h_pwms: n_pwm x W x 4 floats, updated in place with the PWM the reference's loop ends on (before the
  * extra normalisation of the IUPACPattern(ori, pwm) constructor).  Three modes (option "em_fast"):
  *   2  serial: the reference's float32 arithmetic including the ORDER in which it adds the 4^W weights of a PWM
- *      cell (src/peng.cpp:121-127) -- PWMs, iteration counts and `change` are the reference's bit for bit.  One wave
- *      pair per PWM walks each cell's terms in sequence: ~2 ms per iteration at W = 10 for up to a CU-count of PWMs
- *      (11 ms for 1000), 16x that at W = 12.  What a caller needs when discrete decisions follow (motif merging compares
- *      similarity scores that are exactly tied in real arithmetic for reverse-complement twins); the CLI's default.
+ *      cell (src/peng.cpp:121-127) -- PWMs, iteration counts and `change` are the reference's bit for bit.  From
+ *      W = 8 on a cell's chain of roundings is evaluated by one wave as a scan (csrc/seqsum.h; option
+ *      "em_serial_scan" = 0 selects the dependent-addition fold, which also takes any PWM with a negative or
+ *      non-finite weight).  What a caller needs when discrete decisions follow (motif merging compares similarity
+ *      scores that are exactly tied in real arithmetic for reverse-complement twins); the CLI's default.
  *   0  the reference's float32 terms (three divisions per k-mer weight), summed in fp64 through a fixed tree.
  *   1  (library default) the weight c*s / (1 + s/(prod/bg)) evaluated as c*s*prod / (prod + s*bg) with one
  *      reciprocal (~1 ulp per term), fp64 tree sums: the throughput mode, 2.3e12 PWM-k-mer evaluations/s.
@@ -225,6 +226,13 @@ int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturati
 int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold,
                     int max_iterations, const uint32_t* d_counts, const float* d_bg, int32_t* d_state,
                     float* d_change);
+
+/* ---- sequential float32 sums (the summation order of src/peng.cpp:121-127 on plain arrays) ---------------------
+ * d_out[i] = ((0 + t[0]) + t[1]) + ... over the chain_len floats at d_terms + i * chain_len, every addition rounded
+ * to float32 like a left-to-right CPU loop: bit-exact, including denormals and overflow to +inf.  Chains of
+ * non-negative finite terms are evaluated by the scan of csrc/seqsum.h (one wave per chain, 4096 terms per step);
+ * a chain with a negative, infinite or NaN term is summed by a plain loop on the device.  Device pointers. */
+int pengk_sequential_sum_f32(pengk_ctx* ctx, const float* d_terms, uint64_t n_chains, uint64_t chain_len, float* d_out);
 
 /* ---- motif similarity grid (Peng::merge_iupac_patterns' inner loops, src/peng.cpp:251-272, over
  *      IUPACPattern::calculate_S, src/iupac_pattern.cpp:568-615) -------------------------------------------------

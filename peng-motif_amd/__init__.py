@@ -26,7 +26,7 @@ EXPORTS = [
     "pengk_memset", "pengk_host_alloc", "pengk_host_free", "pengk_timer_create", "pengk_timer_record", "pengk_timer_elapsed_ms", "pengk_timer_destroy",
     "pengk_pack", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
     "pengk_count", "pengk_count_bg", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
-    "pengk_seed_candidates", "pengk_iupac_aggregate", "pengk_em", "pengk_em_device", "pengk_motif_similarity",
+    "pengk_seed_candidates", "pengk_iupac_aggregate", "pengk_em", "pengk_em_device", "pengk_sequential_sum_f32", "pengk_motif_similarity",
     "pengk_comm_unique_id", "pengk_comm_init", "pengk_comm_init_env", "pengk_comm_info", "pengk_comm_destroy",
     "pengk_allreduce_tables", "pengk_comm_check_bin_bound", "pengk_allgather",
 ]
@@ -96,6 +96,7 @@ def lib():
         L.pengk_iupac_aggregate.argtypes = [vp, C.c_int, C.c_int, vp, i64, vp, vp, vp, vp]
         L.pengk_em.argtypes = [vp, C.c_int, i64, vp, f32, f32, C.c_int, vp, vp, vp, vp]
         L.pengk_em_device.argtypes = [vp, C.c_int, i64, vp, f32, f32, C.c_int, vp, vp, vp, vp]
+        L.pengk_sequential_sum_f32.argtypes = [vp, vp, u64, u64, vp]
         L.pengk_motif_similarity.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp]
         L.pengk_comm_unique_id.argtypes = [vp]
         L.pengk_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
@@ -325,6 +326,15 @@ class Context:
         _check(lib().pengk_em(self.h, W, n, p.ctypes.data, saturation, threshold, max_iterations, _ptr(counts), _ptr(bg),
                               iters.ctypes.data, change.ctypes.data))
         return p, iters, change
+
+    def sequential_sum(self, terms):
+        """left-to-right float32 sums of the rows of a 2-D array (pengk_sequential_sum_f32)"""
+        t = np.ascontiguousarray(terms, np.float32)
+        t = t.reshape(1, -1) if t.ndim == 1 else t
+        d_t = DeviceArray.from_host(self, t.reshape(-1)) if t.size else None
+        d_o = DeviceArray.from_host(self, np.zeros(max(t.shape[0], 1), np.float32))
+        _check(lib().pengk_sequential_sum_f32(self.h, _ptr(d_t) if d_t is not None else None, t.shape[0], t.shape[1], _ptr(d_o)))
+        return d_o.to_host()[:t.shape[0]]
 
     def em_device(self, W, n_pwm, d_pwms, counts, bg, d_state, d_change, saturation=1e4, threshold=0.08, max_iterations=10):
         _check(lib().pengk_em_device(self.h, W, n_pwm, _ptr(d_pwms), saturation, threshold, max_iterations, _ptr(counts),

@@ -144,6 +144,11 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     ctx->em_fast = (int)value;
     return PENGK_OK;
   }
+  if (strcmp(name, "em_serial_scan") == 0) {
+    if (value < 0 || value > 1) return fail(PENGK_ERR_ARG, "em_serial_scan must be 0 (dependent additions) or 1 (scan)");
+    ctx->em_serial_scan = (int)value;
+    return PENGK_OK;
+  }
   if (strcmp(name, "iupac_group_bytes") == 0) {
     ctx->iupac_group_bytes = (uint64_t)value;
     return PENGK_OK;
@@ -450,6 +455,12 @@ int pengk_motif_similarity(pengk_ctx* ctx, int n, const float* h_pwm, const floa
   PENGK_HIP(hipMemcpyAsync(h_out, base + o_out, (size_t)pairs * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   PENGK_HIP(hipStreamSynchronize(ctx->stream));
   return PENGK_OK;
+}
+
+int pengk_sequential_sum_f32(pengk_ctx* ctx, const float* d_terms, uint64_t n_chains, uint64_t chain_len, float* d_out) {
+  if (!ctx || (!d_terms && n_chains && chain_len) || (!d_out && n_chains)) return fail(PENGK_ERR_ARG, "pengk_sequential_sum_f32: NULL argument");
+  PENGK_ENTER(ctx);
+  return launch_sequential_sum(ctx, d_terms, n_chains, chain_len, d_out);
 }
 
 int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,

@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "pengk_internal.h"
+#include "seqsum.h"
 
 namespace pengk {
 namespace {
@@ -309,7 +310,8 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 template <int W>
 __global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
                                                          const uint32_t* __restrict__ counts, const float* __restrict__ bg,
-                                                         float saturation, float* __restrict__ wbuf) {
+                                                         float saturation, float* __restrict__ wbuf,
+                                                         uint32_t* __restrict__ bad) {
   const int pw = blockIdx.y;
   if (state[2 * pw + 1] == 0) return;
   __shared__ float s_pwm[W * 4];
@@ -322,7 +324,11 @@ __global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict
 #pragma unroll
     for (int p = 0; p < W; ++p) pr = pr * s_pwm[p * 4 + ((x >> (2 * p)) & 3u)];
     const float odds = pr / bg[x];
-    out[x] = ((float)counts[x] * saturation) / (1 + saturation / odds);  // :124-125
+    const float v = ((float)counts[x] * saturation) / (1 + saturation / odds);  // :124-125
+    out[x] = v;
+    // a negative or non-finite weight (degenerate PWM / background entries): this PWM's cells are summed by the plain
+    // serial fold instead of the scan (seqsum.h)
+    if (__float_as_uint(v) > 0x7F7FFFFFu) bad[pw] = 1u;
   }
 }
 
@@ -350,11 +356,13 @@ struct FoldGeo {
 
 template <int W>
 __global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
-                                                      double* __restrict__ partials) {
+                                                      double* __restrict__ partials, const uint32_t* __restrict__ bad,
+                                                      int only_bad) {
   using F = FoldGeo<W>;
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int pw = blockIdx.y;
   if (state[2 * pw + 1] == 0) return;
+  if (only_bad && !bad[pw]) return;  // em_fold_scan_kernel summed this PWM
   const uint32_t p = blockIdx.x;  // position
   const uint32_t np = 1u << (2 * W);
   const float* w = wbuf + (size_t)pw * np;
@@ -458,15 +466,75 @@ __global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict_
   if (wave == 0 && lane < 4u) partials[(size_t)pw * (W * 4) + p * 4u + lane] = (double)acc;  // layout of EmGeo<W, 16>
 }
 
+// The same sums -- the same roundings, seqsum.h -- by one wave per cell: a cell's 4^(W-1) terms in blocks of 4096, each
+// block fetched with coalesced loads, spread over 64 LDS rows of 64 consecutive terms, and evaluated as 64 stretches
+// that the wave composes.  The chain is walked in 4^(W-1) / 4096 steps of ~10^3 cycles instead of 4^(W-1) dependent
+// additions (W = 10: 0.59 -> ~0.05 ms per iteration), and a batch of PWMs fills the chip with 4 W waves per PWM.
+template <int W>
+struct EmTerms {
+  typedef seqsum::f4 f4;
+  const float* __restrict__ w;  // the PWM's weight table (x order)
+  uint32_t p, a;                // the cell: terms are the x whose digit p is a, ascending
+  // term c of the cell is x = [c's digits p.. | a | c's digits 0..p-1]
+  __device__ __forceinline__ uint32_t x_of(uint32_t c) const {
+    return ((c >> (2u * p)) << (2u * p + 2u)) | (a << (2u * p)) | (c & ((1u << (2u * p)) - 1u));
+  }
+  __device__ __forceinline__ void load(uint32_t b, uint32_t lane, float (&R)[64]) const {
+    if (p == 0u) {  // every fourth x: one dword per term, term 64 k + lane of the block in R[k]
+#pragma unroll
+      for (uint32_t k = 0; k < 64u; ++k) R[k] = w[4u * (b * seqsum::BLOCK + 64u * k + lane) + a];
+    } else {        // runs of 4^p >= 4 consecutive x: 16-byte loads, terms 256 k + 4 lane .. + 3 in R[4 k ..]
+#pragma unroll
+      for (uint32_t k = 0; k < 16u; ++k) {
+        const f4 v = *reinterpret_cast<const f4*>(w + x_of(b * seqsum::BLOCK + 256u * k + 4u * lane));
+        R[4u * k] = v.x;
+        R[4u * k + 1u] = v.y;
+        R[4u * k + 2u] = v.z;
+        R[4u * k + 3u] = v.w;
+      }
+    }
+  }
+  __device__ __forceinline__ void deposit(uint32_t lane, const float (&R)[64], float* lds) const {
+    if (p == 0u) {
+#pragma unroll
+      for (uint32_t k = 0; k < 64u; ++k) lds[k * seqsum::SEG_STRIDE + lane] = R[k];
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < 16u; ++k) {
+        f4 v;
+        v.x = R[4u * k];
+        v.y = R[4u * k + 1u];
+        v.z = R[4u * k + 2u];
+        v.w = R[4u * k + 3u];
+        *reinterpret_cast<f4*>(lds + (4u * k + (lane >> 4)) * seqsum::SEG_STRIDE + 4u * (lane & 15u)) = v;
+      }
+    }
+  }
+  __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)
+};
+
+template <int W>
+__global__ __launch_bounds__(64) void em_fold_scan_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
+                                                          double* __restrict__ partials, const uint32_t* __restrict__ bad) {
+  static_assert((1u << (2 * W - 2)) % seqsum::BLOCK == 0u, "whole blocks per cell");
+  const int pw = blockIdx.y;
+  if (state[2 * pw + 1] == 0 || bad[pw]) return;
+  __shared__ __attribute__((aligned(16))) float lds[seqsum::LDS_FLOATS];
+  const EmTerms<W> src{wbuf + ((size_t)pw << (2 * W)), blockIdx.x >> 2, blockIdx.x & 3u};
+  const float s = seqsum::fold_chain<EmTerms<W>, false>(src, (1u << (2 * W - 2)) / seqsum::BLOCK, lds, threadIdx.x);
+  if (threadIdx.x == 0) partials[(size_t)pw * (W * 4) + blockIdx.x] = (double)s;  // cell (p, a) = 4 p + a: layout of EmGeo<W, 16>
+}
+
 // One block per PWM: sum the per-block partials in block order, then the reference's float32
 // epilogue: normalise rows (:129), change = sum |new - old| (:132-137), swap (:140-143).
 template <int W, int HIMAX>
 __global__ __launch_bounds__(64) void em_finalize_kernel(float* __restrict__ pwms, int32_t* __restrict__ state,
                                                          float* __restrict__ change_out, const double* __restrict__ partials,
-                                                         float threshold, int max_it) {
+                                                         float threshold, int max_it, uint32_t* __restrict__ bad) {
   using G = EmGeo<W, HIMAX>;
   const int pw = blockIdx.x;
   if (state[2 * pw + 1] == 0) return;
+  if (bad && threadIdx.x == 0) bad[pw] = 0u;  // serial mode: the next iteration's weights set it again if need be
   __shared__ float s_new[W * 4];
   const int e = threadIdx.x;
   if (e < G::CELLS) {
@@ -541,7 +609,8 @@ int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, f
                          ctx->stream, d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_counts, d_bg, saturation,
                          ctx->d_em_partials, (int)nb);
       hipLaunchKernelGGL((em_finalize_kernel<W, HIMAX>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
-                         d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it);
+                         d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
+                         (uint32_t*)nullptr);
     }
     PENGK_HIP(hipGetLastError());
   }
@@ -565,18 +634,32 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   if (batch > 65535) batch = 65535;  // gridDim.y
   int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, (size_t)batch * np * sizeof(float));
   if (rc) return rc;
-  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, (size_t)batch * G::CELLS * sizeof(double));
+  // partials: one row of cells per PWM, and behind them one flag per PWM ("has a weight the scan cannot take")
+  const size_t flags_at = (size_t)batch * G::CELLS * sizeof(double);
+  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, flags_at + (size_t)batch * sizeof(uint32_t));
   if (rc) return rc;
+  uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_em_partials) + flags_at);
+  PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)batch * sizeof(uint32_t), ctx->stream));
+  // cells of at least four blocks are summed by the scan (seqsum.h); the dependent-addition fold takes the short
+  // chains of W <= 6 and any PWM whose weights the scan cannot take
+  constexpr bool SCAN = (1u << (2 * W - 2)) >= 4u * seqsum::BLOCK;
+  const bool scan = SCAN && ctx->em_serial_scan != 0;
   const unsigned wb = (unsigned)std::min<size_t>((np + 255) / 256, 1024);
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
     for (int it = 0; it < max_it; ++it) {
       hipLaunchKernelGGL((em_weights_kernel<W>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
-                         d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables);
+                         d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
+      if constexpr (SCAN) {
+        if (scan)
+          hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)nb), dim3(64), 0, ctx->stream,
+                             d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad);
+      }
       hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,
-                         ctx->d_em_tables, ctx->d_em_partials);
+                         ctx->d_em_tables, ctx->d_em_partials, bad, scan ? 1 : 0);
       hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
-                         d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it);
+                         d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
+                         bad);
     }
     PENGK_HIP(hipGetLastError());
   }

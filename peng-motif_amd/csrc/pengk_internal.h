@@ -39,6 +39,7 @@ struct pengk_ctx {
   uint64_t n_windows_hint = 0;  // total windows of the attached items (0 = unknown: n_items * item_windows)
   uint64_t key_cap_override = 0; // test hook: entries per bucket region (0 = sized from the window count)
   uint64_t iupac_group_bytes = 0; // test hook: scratch budget of one group of large K4 patterns (0 = 1 GiB)
+  int em_serial_scan = 1;       // K5 serial mode: 1 = cells summed by the parallel scan of seqsum.h, 0 = by dependent additions
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms
   int scatter_blocks_per_cu = 0; // tuning hook: workgroups per CU of the partitioned scan (0 = default)
@@ -99,6 +100,7 @@ int launch_stats(pengk_ctx* ctx, int W, int both, int k, int max_k, const float*
                  const uint32_t* d_counts, float* d_bgprob, float* d_expected, float* d_logp, float* d_z);
 int launch_seed_candidates(pengk_ctx* ctx, int W, const float* d_z, const uint32_t* d_counts, float z_threshold,
                            uint32_t count_threshold, uint32_t cap, uint32_t* d_n, uint32_t* d_ids, float* d_zs);
+int launch_sequential_sum(pengk_ctx* ctx, const float* d_terms, uint64_t n_chains, uint64_t chain_len, float* d_out);
 int launch_similarity(pengk_ctx* ctx, int n, const float* d_pwm, const float* d_comp, const int32_t* d_len,
                       const uint64_t* d_sites, int both, const float* h_bg, int first_new, float* d_out);
 int launch_iupac(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids, int64_t n, const uint32_t* d_counts,

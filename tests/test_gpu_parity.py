@@ -741,6 +741,46 @@ def test_em_serial_mode_many_pwms_in_batches(ctx, golden_dir):
         assert np.float32(change[i]).view(np.uint32) == np.float32(ch0).view(np.uint32)
 
 
+@pytest.mark.parametrize("name", ["mafk100_w8_both", "mafk_w10_plus"])
+def test_em_serial_scan_equals_the_dependent_addition_fold(ctx, golden_dir, name):
+    """The serial mode sums a cell's weights with a wave-wide scan (csrc/seqsum.h, option em_serial_scan = 1, default)
+    or, as in the first rounds, by dependent additions (0).  Both must give the same bits on every PWM -- including
+    degenerate PWMs whose weights are NaN (a zero PWM entry over a zero background entry: 0 / 0), which the scan hands
+    to the dependent-addition fold PWM by PWM."""
+    r = cpu_pipeline(golden_dir, name)
+    W, K = r["W"], r["K"]
+    d = gpu_tables(ctx, r)
+    bgk = d["bgprob"].to_host()[K].copy()
+    order = np.lexsort((np.arange(4 ** W), -r["counts"].astype(np.int64)))[:40]
+    pwms = np.full((len(order), W, 4), 0.1, np.float32)
+    for i, x in enumerate(order):
+        for p_ in range(W):
+            pwms[i, p_, (int(x) >> (2 * p_)) & 3] = 0.7
+    rng = np.random.default_rng(4)
+    pwms[5:20] = rng.dirichlet(np.ones(4), size=(15, W)).astype(np.float32)
+    pwms[7, 3] = [0.0, 0.5, 0.5, 0.0]     # zero PWM entries: weights of 0 for three quarters... and NaN where bg is 0 too
+    pwms[8, 0] = [1.0, 0.0, 0.0, 0.0]
+    bgk[5] = 0.0                          # k-mer 5 = "CCAAAA..." : digit 0 is C, digit 1 is C
+    bgk[12345 % (4 ** W)] = 0.0
+    bg_k = pk.DeviceArray.from_host(ctx, bgk)
+    out = {}
+    ctx.set_option("em_fast", 2)
+    try:
+        for scan in (1, 0):
+            ctx.set_option("em_serial_scan", scan)
+            out[scan] = ctx.em(W, pwms, d["counts"], bg_k, 1e4, 0.0, 3)
+    finally:
+        ctx.set_option("em_serial_scan", 1)
+        ctx.set_option("em_fast", 1)
+    assert out[1][0].tobytes() == out[0][0].tobytes()
+    assert out[1][1].tolist() == out[0][1].tolist() and out[1][2].tobytes() == out[0][2].tobytes()
+    assert np.isnan(out[1][0][8]).any() or np.isnan(out[1][0][7]).any()   # the degenerate ones did go through NaN weights
+    assert np.isfinite(out[1][0][0]).all()
+    # and a healthy PWM of the same batch still matches the oracle
+    p0, it0, ch0 = po.em(W, r["counts"], bgk, pwms[0], 1e4, 0.0, 3, mode=0, final_norm=False)
+    assert bits_equal(out[1][0][0], p0)
+
+
 @pytest.mark.parametrize("name", ["mafk_w10_both", "mafk_w10_plus", "mafk100_w8_both"])
 def test_seed_candidates_on_device(ctx, golden_dir, name):
     """pengk_seed_candidates compacts exactly the ids the reference's walk can reach (z >= threshold, count >= threshold,
