@@ -513,16 +513,29 @@ struct EmTerms {
   __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)
 };
 
+// Workgroup -> (PWM, cell): consecutive workgroups go to consecutive XCDs (8 on gfx950, each with its own 4 MiB L2), so
+// the 4 W cells of a PWM are given to ONE XCD: a PWM's weight table (4^W floats, 4 MiB at W = 10) is read once per
+// position, and the cells of positions 0 .. W-3 walk it side by side within a 256 KiB window -- from that XCD's L2
+// instead of W times across the fabric (the scan is bound by those reads, not by its arithmetic).  The grid is padded to
+// whole groups of 8 PWMs; workgroups of the padding leave at once.
 template <int W>
 __global__ __launch_bounds__(64) void em_fold_scan_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
-                                                          double* __restrict__ partials, const uint32_t* __restrict__ bad) {
+                                                          double* __restrict__ partials, const uint32_t* __restrict__ bad,
+                                                          uint32_t n_pwm) {
   static_assert((1u << (2 * W - 2)) % seqsum::BLOCK == 0u, "whole blocks per cell");
-  const int pw = blockIdx.y;
-  if (state[2 * pw + 1] == 0 || bad[pw]) return;
+  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+  const uint32_t cell = slot % (4u * W), pw = (lin & 7u) + 8u * (slot / (4u * W));
+  if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
+#ifdef PENGK_SKIP_LOWP
+  if ((cell >> 2) < PENGK_SKIP_LOWP) {  // timing experiment: leave the low positions out
+    if (threadIdx.x == 0) partials[(size_t)pw * (W * 4) + cell] = 1.0;
+    return;
+  }
+#endif
   __shared__ __attribute__((aligned(16))) float lds[seqsum::LDS_FLOATS];
-  const EmTerms<W> src{wbuf + ((size_t)pw << (2 * W)), blockIdx.x >> 2, blockIdx.x & 3u};
+  const EmTerms<W> src{wbuf + ((size_t)pw << (2 * W)), cell >> 2, cell & 3u};
   const float s = seqsum::fold_chain<EmTerms<W>, false>(src, (1u << (2 * W - 2)) / seqsum::BLOCK, lds, threadIdx.x);
-  if (threadIdx.x == 0) partials[(size_t)pw * (W * 4) + blockIdx.x] = (double)s;  // cell (p, a) = 4 p + a: layout of EmGeo<W, 16>
+  if (threadIdx.x == 0) partials[(size_t)pw * (W * 4) + cell] = (double)s;  // cell (p, a) = 4 p + a: layout of EmGeo<W, 16>
 }
 
 // One block per PWM: sum the per-block partials in block order, then the reference's float32
@@ -617,6 +630,21 @@ int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, f
   return PENGK_OK;
 }
 
+#ifdef PENGK_SEQSUM_STATS
+}  // namespace
+}  // namespace pengk
+extern "C" __attribute__((visibility("default"))) int pengk_debug_seqsum_stats(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pengk::seqsum::g_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pengk::seqsum::g_stats), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+namespace pengk {
+namespace {
+#endif
+
 template <int W>
 int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
                   const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
@@ -631,7 +659,7 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   int64_t batch = (int64_t)(budget / (np * sizeof(float)));
   if (batch < 1) batch = 1;
   if (batch > n_pwm) batch = n_pwm;
-  if (batch > 65535) batch = 65535;  // gridDim.y
+  if (batch > 65528) batch = 65528;  // gridDim.y, in whole groups of 8 PWMs
   int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, (size_t)batch * np * sizeof(float));
   if (rc) return rc;
   // partials: one row of cells per PWM, and behind them one flag per PWM ("has a weight the scan cannot take")
@@ -652,8 +680,8 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
                          d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
       if constexpr (SCAN) {
         if (scan)
-          hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)nb), dim3(64), 0, ctx->stream,
-                             d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad);
+          hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(64), 0, ctx->stream,
+                             d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad, (uint32_t)nb);
       }
       hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,
                          ctx->d_em_tables, ctx->d_em_partials, bad, scan ? 1 : 0);

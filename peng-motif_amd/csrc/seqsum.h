@@ -39,6 +39,15 @@ constexpr uint32_t INF_BITS = 0x7F800000u;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+#ifdef PENGK_SEQSUM_STATS  // developer build: where a chain's time goes (tools/seqsum_stats.py)
+__device__ unsigned long long g_stats[8];
+#define PENGK_STAT_ADD(i, v) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+#define PENGK_CLOCK() __builtin_amdgcn_s_memtime()
+#else
+#define PENGK_STAT_ADD(i, v) do { } while (0)
+#define PENGK_CLOCK() 0ull
+#endif
+
 __device__ __forceinline__ uint32_t bits(float v) { return __float_as_uint(v); }
 
 struct Bases {
@@ -67,101 +76,149 @@ __device__ __forceinline__ void compose(float& a0, float& a1, float b0, float b1
   a1 = a1 + ((bits(a1) & 1u) ? d1 : d0);
 }
 
-// the 64 terms of an LDS row, added in order to two running values
-__device__ __forceinline__ void run2(const float* row, float& x0, float& x1) {
-  const f4* q = reinterpret_cast<const f4*>(row);
+// An LDS row's 64 terms into registers: all sixteen 16-byte reads are issued before the first value is used (left to
+// itself the compiler keeps two reads in flight and the chain of additions waits for LDS eight times per row).
+struct Row {
+  f4 q[SEG / 4u];
+  __device__ __forceinline__ void read(const float* row) {
+    const f4* src = reinterpret_cast<const f4*>(row);
 #pragma unroll
-  for (uint32_t j = 0; j < SEG / 4u; ++j) {
-    const f4 v = q[j];
-    x0 += v.x; x1 += v.x;
-    x0 += v.y; x1 += v.y;
-    x0 += v.z; x1 += v.z;
-    x0 += v.w; x1 += v.w;
+    for (uint32_t j = 0; j < SEG / 4u; ++j) q[j] = src[j];
+    static_assert(SEG == 64u, "sixteen quads");
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
+                 "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]));
   }
+  // the terms added in order to two running values / to one
+  __device__ __forceinline__ void run2(float& x0, float& x1) const {
+#pragma unroll
+    for (uint32_t j = 0; j < SEG / 4u; ++j) {
+      x0 += q[j].x; x1 += q[j].x;
+      x0 += q[j].y; x1 += q[j].y;
+      x0 += q[j].z; x1 += q[j].z;
+      x0 += q[j].w; x1 += q[j].w;
+    }
+  }
+  __device__ __forceinline__ float run1(float x) const {
+#pragma unroll
+    for (uint32_t j = 0; j < SEG / 4u; ++j) {
+      x += q[j].x;
+      x += q[j].y;
+      x += q[j].z;
+      x += q[j].w;
+    }
+    return x;
+  }
+};
+
+// v of the lane d places down in this lane's row of 16 (DPP row_shr), `self` where the row has no such lane
+template <int D>
+__device__ __forceinline__ float row_shr(float self, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(self), __float_as_int(v), 0x110 + D, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float run1(const float* row, float x) {
-  const f4* q = reinterpret_cast<const f4*>(row);
-#pragma unroll
-  for (uint32_t j = 0; j < SEG / 4u; ++j) {
-    const f4 v = q[j];
-    x += v.x;
-    x += v.y;
-    x += v.z;
-    x += v.w;
-  }
-  return x;
+__device__ __forceinline__ float lane_value(float v, int l) {  // wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
 // One block: lds holds 64 rows of 64 terms (row l = terms 64 l .. 64 l + 63 of the block); s = the sum in front of
 // the block.  Returns the sum behind it.  Wave-uniform.
+//
+// Every lane evaluates its row from the two bases; an inclusive prefix composition (four DPP steps inside the rows of
+// 16 lanes, the three row boundaries with wave-uniform values) gives every lane the sum behind its row, valid if nothing
+// left the binade up to there.  No lane flagged: lane 63 holds the result.  Otherwise the first flagged row is added
+// the reference's way and the rows behind it are evaluated again in the new binade.
 __device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, float s) {
-  const float* row = lds + lane * SEG_STRIDE;
+  Row mine;
+  mine.read(lds + lane * SEG_STRIDE);
   uint32_t first = 0;  // rows < first are already part of s
   for (;;) {
+    PENGK_STAT_ADD(1, 1);
     if (bits(s) >= INF_BITS) return s;  // +inf + t = +inf
     const Bases B = bases_of(s);
-    float x0 = B.b0, x1 = B.b1;
-    run2(row, x0, x1);
+    float i0 = B.b0, i1 = B.b1;
+    mine.run2(i0, i1);
     if (lane < first) {
-      x0 = B.b0;
-      x1 = B.b1;
+      i0 = B.b0;
+      i1 = B.b1;
     }
-    // ordered reduction: after step d lane l (a multiple of 2d) holds rows l .. l + 2d - 1
-    float t0 = x0, t1 = x1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const float b0 = __shfl_down(t0, d, 64), b1 = __shfl_down(t1, d, 64);
-      compose(t0, t1, b0, b1, B);
+    // inclusive prefix inside each row of 16 lanes: (rows l-d .. of the earlier lanes) then (this lane's)
+#define PENGK_ROW_STEP(D)                                                     \
+    {                                                                          \
+      float a0 = row_shr<D>(B.b0, i0), a1 = row_shr<D>(B.b1, i1);              \
+      compose(a0, a1, i0, i1, B);                                              \
+      i0 = a0;                                                                 \
+      i1 = a1;                                                                 \
     }
-    const float T0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)bits(t0)));
-    const float T1 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)bits(t1)));
+    PENGK_ROW_STEP(1) PENGK_ROW_STEP(2) PENGK_ROW_STEP(4) PENGK_ROW_STEP(8)
+#undef PENGK_ROW_STEP
+    // the rows of 16: totals at lanes 15, 31, 47; what lies in front of rows 1, 2, 3 (wave-uniform)
+    float p0 = lane_value(i0, 15), p1 = lane_value(i1, 15);  // in front of row 1
+    float q0 = p0, q1 = p1;
+    compose(q0, q1, lane_value(i0, 31), lane_value(i1, 31), B);  // in front of row 2
+    float r0 = q0, r1 = q1;
+    compose(r0, r1, lane_value(i0, 47), lane_value(i1, 47), B);  // in front of row 3
+    const uint32_t rw = lane >> 4;
+    float f0 = rw == 1u ? p0 : rw == 2u ? q0 : rw == 3u ? r0 : B.b0;
+    float f1 = rw == 1u ? p1 : rw == 2u ? q1 : rw == 3u ? r1 : B.b1;
+    compose(f0, f1, i0, i1, B);  // rows first .. this lane's
     const uint32_t par = bits(s) & 1u;
-    const float out = s + (par ? T1 - B.b1 : T0 - B.b0);
-    if (bits(out) < B.limit) return out;  // the whole block stayed in the binade of s
-    // some row leaves the binade: inclusive prefix composition, rows first .. l
-    float i0 = x0, i1 = x1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      float a0 = __shfl_up(i0, d, 64), a1 = __shfl_up(i1, d, 64);
-      compose(a0, a1, i0, i1, B);
-      if (lane >= (uint32_t)d) {
-        i0 = a0;
-        i1 = a1;
-      }
-    }
-    const float end = s + (par ? i1 - B.b1 : i0 - B.b0);  // the sum behind row l, exact if nothing crossed up to there
+    const float end = s + (par ? f1 - B.b1 : f0 - B.b0);  // the sum behind this lane's row, exact if nothing crossed up to there
     const unsigned long long flagged = __builtin_amdgcn_ballot_w64(bits(end) >= B.limit);
-    const int L = flagged ? __builtin_ctzll(flagged) : 63;  // (flagged != 0: the last row carries the block total)
+    if (!flagged) return lane_value(end, 63);  // the whole block stayed in the binade of s
+    const int L = __builtin_ctzll(flagged);
     float v = s;
-    if (L > 0) v = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)bits(end), L - 1));
-    s = run1(lds + (uint32_t)L * SEG_STRIDE, v);  // the reference's own additions through row L, all lanes alike
+    if (L > 0) v = lane_value(end, L - 1);
+    Row crossing;
+    crossing.read(lds + (uint32_t)L * SEG_STRIDE);
+    s = crossing.run1(v);  // the reference's own additions through row L, all lanes alike
     first = (uint32_t)L + 1u;
     if (first == 64u) return s;
   }
 }
 
 // The term source of a chain: load(b, lane, R) fetches block b into 64 registers, deposit(lane, R, lds) spreads them
-// over the LDS rows.  fold_chain overlaps the fetch of block b + 1 with the evaluation of block b.
+// over the LDS rows.  fold_chain overlaps the fetch of blocks b + 1 and b + 2 with the evaluation of block b.
 // CHECK: look at every term; a chain with a negative / non-finite term is summed by the plain loop `serial`.
 template <class Source, bool CHECK>
 __device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks, float* lds, uint32_t lane) {
-  float R[64];
-  src.load(0u, lane, R);
+  // two blocks in flight (a block's loads take ~2 us to come back, its evaluation ~0.7 us)
+  float RA[64], RB[64];
   float s = 0.0f;
-#pragma unroll 1
-  for (uint32_t b = 0; b < n_blocks; ++b) {
+  bool fallback = false;
+  auto step = [&](uint32_t b, float (&R)[64]) {
     if (CHECK) {
       uint32_t m = 0;
 #pragma unroll
       for (int k = 0; k < 64; ++k) m = max(m, bits(R[k]));
-      if (__builtin_amdgcn_ballot_w64(m > 0x7F7FFFFFu)) return src.serial();  // wave-uniform
+      if (__builtin_amdgcn_ballot_w64(m > 0x7F7FFFFFu)) fallback = true;  // wave-uniform
     }
+    const unsigned long long c0 = PENGK_CLOCK();
     src.deposit(lane, R, lds);
-    if (b + 1u < n_blocks) src.load(b + 1u, lane, R);
+#ifdef PENGK_SEQSUM_STATS
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the clock sees the deposit (and the wait for the block's loads)
+#endif
+    const unsigned long long c1 = PENGK_CLOCK();
+#ifndef PENGK_SEQSUM_NOLOAD
+    if (b + 2u < n_blocks) src.load(b + 2u, lane, R);
+#endif
+#ifdef PENGK_SEQSUM_NOEVAL
+    s += lds[lane * SEG_STRIDE];
+#else
     s = fold_block(lds, lane, s);
+#endif
     __builtin_amdgcn_wave_barrier();
+    const unsigned long long c2 = PENGK_CLOCK();
+    PENGK_STAT_ADD(0, 1);
+    PENGK_STAT_ADD(2, c1 - c0);
+    PENGK_STAT_ADD(3, c2 - c1);
+  };
+  src.load(0u, lane, RA);
+  if (n_blocks > 1u) src.load(1u, lane, RB);
+#pragma unroll 1
+  for (uint32_t b = 0; b < n_blocks && !fallback; b += 2u) {
+    step(b, RA);
+    if (b + 1u < n_blocks && !fallback) step(b + 1u, RB);
   }
-  return s;
+  return fallback ? src.serial() : s;
 }
 
 }  // namespace seqsum
