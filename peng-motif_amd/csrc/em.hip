@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 //   em_fold_kernel     one workgroup per position and PWM: the four cells (p, a) walk THEIR terms -- the x whose digit
 //                      p is a, ascending -- from LDS, where loader waves stage them with coalesced loads.
 // ---------------------------------------------------------------------------------------------
-template <int W>
+template <int W, bool T0>
 __global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
                                                          const uint32_t* __restrict__ counts, const float* __restrict__ bg,
                                                          float saturation, float* __restrict__ wbuf,
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict
   if (threadIdx.x < W * 4) s_pwm[threadIdx.x] = pwms[(size_t)pw * W * 4 + threadIdx.x];
   __syncthreads();
   const uint32_t np = 1u << (2 * W);
-  float* out = wbuf + (size_t)pw * np;
+  float* out = wbuf + (size_t)pw * ((size_t)np << (T0 ? 1 : 0));
   for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
     float pr = 1.0f;  // src/peng.cpp:180-197: ((1*pwm[0][x0])*pwm[1][x1])...
 #pragma unroll
@@ -326,6 +326,10 @@ __global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict
     const float odds = pr / bg[x];
     const float v = ((float)counts[x] * saturation) / (1 + saturation / odds);  // :124-125
     out[x] = v;
+    // position 0's cells take every fourth x: a second, permuted copy of the table with the four cells' terms contiguous
+    // (term c of cell a at np + a 4^(W-1) + c) lets the scan fetch them like the cells of position W-1 (otherwise each of
+    // the four cells moves every line and issues four times the loads -- they were the last to finish)
+    if (T0) out[np + (x & 3u) * (np / 4u) + (x >> 2)] = v;
     // a negative or non-finite weight (degenerate PWM / background entries): this PWM's cells are summed by the plain
     // serial fold instead of the scan (seqsum.h)
     if (__float_as_uint(v) > 0x7F7FFFFFu) bad[pw] = 1u;
@@ -357,7 +361,7 @@ struct FoldGeo {
 template <int W>
 __global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
                                                       double* __restrict__ partials, const uint32_t* __restrict__ bad,
-                                                      int only_bad) {
+                                                      int only_bad, uint32_t pwm_stride) {
   using F = FoldGeo<W>;
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int pw = blockIdx.y;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict_
   if (only_bad && !bad[pw]) return;  // em_fold_scan_kernel summed this PWM
   const uint32_t p = blockIdx.x;  // position
   const uint32_t np = 1u << (2 * W);
-  const float* w = wbuf + (size_t)pw * np;
+  const float* w = wbuf + (size_t)pw * pwm_stride;
   __shared__ __attribute__((aligned(16))) float buf[2][4][F::ROW];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t run = 1u << (2 * p);  // a cell's terms come in runs of 4^p consecutive x, one run per 4^(p+1)
@@ -474,40 +478,31 @@ template <int W>
 struct EmTerms {
   typedef seqsum::f4 f4;
   const float* __restrict__ w;  // the PWM's weight table (x order)
-  uint32_t p, a;                // the cell: terms are the x whose digit p is a, ascending
+  uint32_t p, a;                // the cell: terms are the x whose digit p >= 1 is a, ascending
   // term c of the cell is x = [c's digits p.. | a | c's digits 0..p-1]
   __device__ __forceinline__ uint32_t x_of(uint32_t c) const {
     return ((c >> (2u * p)) << (2u * p + 2u)) | (a << (2u * p)) | (c & ((1u << (2u * p)) - 1u));
   }
+  // runs of 4^p >= 4 consecutive x: 16-byte loads, terms 256 k + 4 lane .. + 3 of the block in R[4 k ..]
   __device__ __forceinline__ void load(uint32_t b, uint32_t lane, float (&R)[64]) const {
-    if (p == 0u) {  // every fourth x: one dword per term, term 64 k + lane of the block in R[k]
 #pragma unroll
-      for (uint32_t k = 0; k < 64u; ++k) R[k] = w[4u * (b * seqsum::BLOCK + 64u * k + lane) + a];
-    } else {        // runs of 4^p >= 4 consecutive x: 16-byte loads, terms 256 k + 4 lane .. + 3 in R[4 k ..]
-#pragma unroll
-      for (uint32_t k = 0; k < 16u; ++k) {
-        const f4 v = *reinterpret_cast<const f4*>(w + x_of(b * seqsum::BLOCK + 256u * k + 4u * lane));
-        R[4u * k] = v.x;
-        R[4u * k + 1u] = v.y;
-        R[4u * k + 2u] = v.z;
-        R[4u * k + 3u] = v.w;
-      }
+    for (uint32_t k = 0; k < 16u; ++k) {
+      const f4 v = *reinterpret_cast<const f4*>(w + x_of(b * seqsum::BLOCK + 256u * k + 4u * lane));
+      R[4u * k] = v.x;
+      R[4u * k + 1u] = v.y;
+      R[4u * k + 2u] = v.z;
+      R[4u * k + 3u] = v.w;
     }
   }
   __device__ __forceinline__ void deposit(uint32_t lane, const float (&R)[64], float* lds) const {
-    if (p == 0u) {
 #pragma unroll
-      for (uint32_t k = 0; k < 64u; ++k) lds[k * seqsum::SEG_STRIDE + lane] = R[k];
-    } else {
-#pragma unroll
-      for (uint32_t k = 0; k < 16u; ++k) {
-        f4 v;
-        v.x = R[4u * k];
-        v.y = R[4u * k + 1u];
-        v.z = R[4u * k + 2u];
-        v.w = R[4u * k + 3u];
-        *reinterpret_cast<f4*>(lds + (4u * k + (lane >> 4)) * seqsum::SEG_STRIDE + 4u * (lane & 15u)) = v;
-      }
+    for (uint32_t k = 0; k < 16u; ++k) {
+      f4 v;
+      v.x = R[4u * k];
+      v.y = R[4u * k + 1u];
+      v.z = R[4u * k + 2u];
+      v.w = R[4u * k + 3u];
+      *reinterpret_cast<f4*>(lds + (4u * k + (lane >> 4)) * seqsum::SEG_STRIDE + 4u * (lane & 15u)) = v;
     }
   }
   __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)
@@ -533,7 +528,10 @@ __global__ __launch_bounds__(64) void em_fold_scan_kernel(const int32_t* __restr
   }
 #endif
   __shared__ __attribute__((aligned(16))) float lds[seqsum::LDS_FLOATS];
-  const EmTerms<W> src{wbuf + ((size_t)pw << (2 * W)), cell >> 2, cell & 3u};
+  constexpr uint32_t NP = 1u << (2 * W);
+  const float* w = wbuf + (size_t)pw * 2u * NP;
+  // position 0 reads the weights kernel's second copy, where its four cells lie like those of position W-1
+  const EmTerms<W> src = (cell >> 2) == 0u ? EmTerms<W>{w + NP, (uint32_t)(W - 1), cell & 3u} : EmTerms<W>{w, cell >> 2, cell & 3u};
   const float s = seqsum::fold_chain<EmTerms<W>, false>(src, (1u << (2 * W - 2)) / seqsum::BLOCK, lds, threadIdx.x);
   if (threadIdx.x == 0) partials[(size_t)pw * (W * 4) + cell] = (double)s;  // cell (p, a) = 4 p + a: layout of EmGeo<W, 16>
 }
@@ -656,11 +654,14 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   PENGK_HIP(hipGetLastError());
   const size_t np = (size_t)1 << (2 * W);
   const size_t budget = (size_t)1 << 30;  // weight tables of one batch of PWMs
-  int64_t batch = (int64_t)(budget / (np * sizeof(float)));
+  constexpr bool SCAN = (1u << (2 * W - 2)) >= 4u * seqsum::BLOCK;
+  const bool scan = SCAN && ctx->em_serial_scan != 0;
+  const size_t pwm_stride = scan ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)
+  int64_t batch = (int64_t)(budget / (pwm_stride * sizeof(float)));
   if (batch < 1) batch = 1;
   if (batch > n_pwm) batch = n_pwm;
   if (batch > 65528) batch = 65528;  // gridDim.y, in whole groups of 8 PWMs
-  int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, (size_t)batch * np * sizeof(float));
+  int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, (size_t)batch * pwm_stride * sizeof(float));
   if (rc) return rc;
   // partials: one row of cells per PWM, and behind them one flag per PWM ("has a weight the scan cannot take")
   const size_t flags_at = (size_t)batch * G::CELLS * sizeof(double);
@@ -670,21 +671,23 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)batch * sizeof(uint32_t), ctx->stream));
   // cells of at least four blocks are summed by the scan (seqsum.h); the dependent-addition fold takes the short
   // chains of W <= 6 and any PWM whose weights the scan cannot take
-  constexpr bool SCAN = (1u << (2 * W - 2)) >= 4u * seqsum::BLOCK;
-  const bool scan = SCAN && ctx->em_serial_scan != 0;
   const unsigned wb = (unsigned)std::min<size_t>((np + 255) / 256, 1024);
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
     for (int it = 0; it < max_it; ++it) {
-      hipLaunchKernelGGL((em_weights_kernel<W>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
-                         d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
+      if (scan)
+        hipLaunchKernelGGL((em_weights_kernel<W, true>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
+                           d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
+      else
+        hipLaunchKernelGGL((em_weights_kernel<W, false>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
+                           d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
       if constexpr (SCAN) {
         if (scan)
           hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(64), 0, ctx->stream,
                              d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad, (uint32_t)nb);
       }
       hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,
-                         ctx->d_em_tables, ctx->d_em_partials, bad, scan ? 1 : 0);
+                         ctx->d_em_tables, ctx->d_em_partials, bad, scan ? 1 : 0, (uint32_t)pwm_stride);
       hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
                          d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
                          bad);
