@@ -303,9 +303,11 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 // the motifs' merge and redundancy decisions downstream compare similarity scores that are exactly tied in real
 // arithmetic for reverse-complement twins, so the last bits of those sums decide what the program prints.
 // A cell's sum is inherently sequential, but cells and PWMs are independent and the weights are not:
-//   em_weights_kernel  all weights w(x) of a PWM in parallel (reference float operations), to a scratch table;
-//   em_fold_kernel     one workgroup per position and PWM: the four cells (p, a) walk THEIR terms -- the x whose digit
-//                      p is a, ascending -- from LDS, where loader waves stage them with coalesced loads.
+//   em_weights_kernel    all weights w(x) of a PWM in parallel (reference float operations), to a scratch table;
+//   em_fold_scan_kernel  (W >= 8) one wave per cell evaluates the cell's chain of roundings as a scan (seqsum.h);
+//   em_fold_kernel       (W <= 6, and PWMs with a negative / non-finite weight) one workgroup per position and PWM:
+//                        the four cells (p, a) walk THEIR terms -- the x whose digit p is a, ascending -- from LDS,
+//                        where loader waves stage them with coalesced loads, one dependent addition after the other.
 // ---------------------------------------------------------------------------------------------
 template <int W, bool T0>
 __global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
@@ -472,8 +474,9 @@ __global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict_
 
 // The same sums -- the same roundings, seqsum.h -- by one wave per cell: a cell's 4^(W-1) terms in blocks of 4096, each
 // block fetched with coalesced loads, spread over 64 LDS rows of 64 consecutive terms, and evaluated as 64 stretches
-// that the wave composes.  The chain is walked in 4^(W-1) / 4096 steps of ~10^3 cycles instead of 4^(W-1) dependent
-// additions (W = 10: 0.59 -> ~0.05 ms per iteration), and a batch of PWMs fills the chip with 4 W waves per PWM.
+// that the wave composes.  The chain is walked in 4^(W-1) / 4096 steps of ~1.4 us instead of 4^(W-1) dependent
+// additions (W = 10, 16 PWMs: 0.71 -> 0.09 ms per iteration), and a batch of PWMs fills the chip with 4 W waves per PWM.
+// What is left of a step is one wave's own dependent work: 128 additions, the prefix composition, the wait for LDS.
 template <int W>
 struct EmTerms {
   typedef seqsum::f4 f4;
@@ -521,12 +524,6 @@ __global__ __launch_bounds__(64) void em_fold_scan_kernel(const int32_t* __restr
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t cell = slot % (4u * W), pw = (lin & 7u) + 8u * (slot / (4u * W));
   if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
-#ifdef PENGK_SKIP_LOWP
-  if ((cell >> 2) < PENGK_SKIP_LOWP) {  // timing experiment: leave the low positions out
-    if (threadIdx.x == 0) partials[(size_t)pw * (W * 4) + cell] = 1.0;
-    return;
-  }
-#endif
   __shared__ __attribute__((aligned(16))) float lds[seqsum::LDS_FLOATS];
   constexpr uint32_t NP = 1u << (2 * W);
   const float* w = wbuf + (size_t)pw * 2u * NP;

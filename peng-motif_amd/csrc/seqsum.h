@@ -197,14 +197,8 @@ __device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the clock sees the deposit (and the wait for the block's loads)
 #endif
     const unsigned long long c1 = PENGK_CLOCK();
-#ifndef PENGK_SEQSUM_NOLOAD
     if (b + 2u < n_blocks) src.load(b + 2u, lane, R);
-#endif
-#ifdef PENGK_SEQSUM_NOEVAL
-    s += lds[lane * SEG_STRIDE];
-#else
     s = fold_block(lds, lane, s);
-#endif
     __builtin_amdgcn_wave_barrier();
     const unsigned long long c2 = PENGK_CLOCK();
     PENGK_STAT_ADD(0, 1);
