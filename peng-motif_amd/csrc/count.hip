@@ -736,9 +736,21 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
   for (uint32_t s = first + wave; s < last; s += 4) {
     const uint32_t n = fill1[(size_t)s * 32u + b1];  // multiple of GROUP32
     const uint32_t* src = keys1 + ((size_t)s * 32u + b1) * cap1;
-    for (uint32_t i = 0; i < n; i += 64) {  // wave-uniform trip count
-      const uint32_t k = (i + lane < n) ? __builtin_nontemporal_load(&src[i + lane]) : KEY32_INVALID;
-      e.masked(k, k != KEY32_INVALID);
+    // 256 keys per step: one 16-byte load per lane, the next step's already in flight while these four are appended
+    // (one key per lane and step left the wave waiting for every line it asked for).  Padding keys (KEY32_INVALID) need
+    // no test: their bucket bits select the last bucket and their payload bits are KEY_INVALID, which pass B skips.
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 pad = {KEY32_INVALID, KEY32_INVALID, KEY32_INVALID, KEY32_INVALID};
+    const u4* src4 = reinterpret_cast<const u4*>(src);  // slices start on multiples of cap1 (a multiple of 32 entries)
+    const uint32_t n4 = n / 4u;                         // n is a multiple of GROUP32
+    u4 nxt = lane < n4 ? __builtin_nontemporal_load(&src4[lane]) : pad;
+    for (uint32_t i = 0; i < n4; i += 64) {  // wave-uniform trip count
+      const u4 k = nxt;
+      nxt = (i + 64u + lane < n4) ? __builtin_nontemporal_load(&src4[i + 64u + lane]) : pad;
+      e.full(k.x);
+      e.full(k.y);
+      e.full(k.z);
+      e.full(k.w);
     }
   }
   e.drain();
