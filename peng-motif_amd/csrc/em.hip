@@ -486,11 +486,22 @@ struct EmTerms {
   __device__ __forceinline__ uint32_t x_of(uint32_t c) const {
     return ((c >> (2u * p)) << (2u * p + 2u)) | (a << (2u * p)) | (c & ((1u << (2u * p)) - 1u));
   }
-  // runs of 4^p >= 4 consecutive x: 16-byte loads, terms 256 k + 4 lane .. + 3 of the block in R[4 k ..]
+  // runs of 4^p >= 4 consecutive x: 16-byte loads, terms 256 k + 4 lane .. + 3 of the block in R[4 k ..].
+  // x_of(4096 b + r) = F(b) + x_of(r) for r < 4096 (4096 b is a multiple of 4^p, or 4^p a multiple of 4096: no carry
+  // between the two parts of c): the per-lane part, sixteen byte offsets, is computed once (bind), the per-block part
+  // is a scalar -- a load costs no vector instruction (computing x_of per load was a quarter of a step).
+  uint32_t g[16];
+  __device__ __forceinline__ void bind(uint32_t lane) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) g[k] = 4u * x_of(256u * k + 4u * lane);
+  }
   __device__ __forceinline__ void load(uint32_t b, uint32_t lane, float (&R)[64]) const {
+    // wave-uniform (readfirstlane: the base stays in scalar registers, the load takes it plus a 32-bit lane offset)
+    const uint32_t F = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x_of(b * seqsum::BLOCK) - (a << (2u * p))));
+    const char* base = reinterpret_cast<const char*>(w + F);
 #pragma unroll
     for (uint32_t k = 0; k < 16u; ++k) {
-      const f4 v = *reinterpret_cast<const f4*>(w + x_of(b * seqsum::BLOCK + 256u * k + 4u * lane));
+      const f4 v = *reinterpret_cast<const f4*>(base + g[k]);
       R[4u * k] = v.x;
       R[4u * k + 1u] = v.y;
       R[4u * k + 2u] = v.z;
@@ -517,18 +528,19 @@ struct EmTerms {
 // instead of W times across the fabric (the scan is bound by those reads, not by its arithmetic).  The grid is padded to
 // whole groups of 8 PWMs; workgroups of the padding leave at once.
 template <int W>
-__global__ __launch_bounds__(64) void em_fold_scan_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
+__global__ __launch_bounds__(seqsum::CHAIN_THREADS) void em_fold_scan_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
                                                           double* __restrict__ partials, const uint32_t* __restrict__ bad,
                                                           uint32_t n_pwm) {
   static_assert((1u << (2 * W - 2)) % seqsum::BLOCK == 0u, "whole blocks per cell");
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t cell = slot % (4u * W), pw = (lin & 7u) + 8u * (slot / (4u * W));
   if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
-  __shared__ __attribute__((aligned(16))) float lds[seqsum::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[seqsum::CHAIN_LDS_FLOATS];
   constexpr uint32_t NP = 1u << (2 * W);
   const float* w = wbuf + (size_t)pw * 2u * NP;
   // position 0 reads the weights kernel's second copy, where its four cells lie like those of position W-1
-  const EmTerms<W> src = (cell >> 2) == 0u ? EmTerms<W>{w + NP, (uint32_t)(W - 1), cell & 3u} : EmTerms<W>{w, cell >> 2, cell & 3u};
+  EmTerms<W> src = (cell >> 2) == 0u ? EmTerms<W>{w + NP, (uint32_t)(W - 1), cell & 3u} : EmTerms<W>{w, cell >> 2, cell & 3u};
+  src.bind(threadIdx.x & 63u);
   const float s = seqsum::fold_chain<EmTerms<W>, false>(src, (1u << (2 * W - 2)) / seqsum::BLOCK, lds, threadIdx.x);
   if (threadIdx.x == 0) partials[(size_t)pw * (W * 4) + cell] = (double)s;  // cell (p, a) = 4 p + a: layout of EmGeo<W, 16>
 }
@@ -629,9 +641,9 @@ int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, f
 }  // namespace
 }  // namespace pengk
 extern "C" __attribute__((visibility("default"))) int pengk_debug_seqsum_stats(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pengk::seqsum::g_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pengk::seqsum::g_stats), 12 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[12] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(pengk::seqsum::g_stats), z, sizeof z) != hipSuccess) return 1;
   }
   return 0;
@@ -680,7 +692,7 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
                            d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
       if constexpr (SCAN) {
         if (scan)
-          hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(64), 0, ctx->stream,
+          hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(seqsum::CHAIN_THREADS), 0, ctx->stream,
                              d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad, (uint32_t)nb);
       }
       hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,

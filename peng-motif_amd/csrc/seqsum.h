@@ -23,6 +23,7 @@
 //
 // A term with its sign bit set, an infinity or a NaN breaks the monotonicity; callers route such chains to a plain
 // serial loop (em.hip keeps its serial fold kernel for that; fold_chain<.., true> checks and falls back itself).
+// One wave evaluates; a second wave of the workgroup keeps it fed (fold_chain).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,11 +41,21 @@ constexpr uint32_t INF_BITS = 0x7F800000u;
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #ifdef PENGK_SEQSUM_STATS  // developer build: where a chain's time goes (tools/seqsum_stats.py)
-__device__ unsigned long long g_stats[8];
-#define PENGK_STAT_ADD(i, v) do { if (lane == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+__device__ unsigned long long g_stats[12];
+struct Stats {  // per wave, added to g_stats once at the end of the chain
+  unsigned long long v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  __device__ __forceinline__ void flush(uint32_t lane) {
+    if (lane == 0)
+      for (int i = 0; i < 12; ++i) atomicAdd(&g_stats[i], v[i]);
+  }
+};
+#define PENGK_STAT_ADD(i, x) do { st.v[i] += (unsigned long long)(x); } while (0)
 #define PENGK_CLOCK() __builtin_amdgcn_s_memtime()
 #else
-#define PENGK_STAT_ADD(i, v) do { } while (0)
+struct Stats {
+  __device__ __forceinline__ void flush(uint32_t) {}
+};
+#define PENGK_STAT_ADD(i, x) do { } while (0)
 #define PENGK_CLOCK() 0ull
 #endif
 
@@ -126,43 +137,69 @@ __device__ __forceinline__ float lane_value(float v, int l) {  // wave-uniform
 // 16 lanes, the three row boundaries with wave-uniform values) gives every lane the sum behind its row, valid if nothing
 // left the binade up to there.  No lane flagged: lane 63 holds the result.  Otherwise the first flagged row is added
 // the reference's way and the rows behind it are evaluated again in the new binade.
-__device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, float s) {
+__device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, float s, Stats& st) {
+  const unsigned long long k0 = PENGK_CLOCK();
   Row mine;
   mine.read(lds + lane * SEG_STRIDE);
+  const unsigned long long k1 = PENGK_CLOCK();
+  PENGK_STAT_ADD(4, k1 - k0);
   uint32_t first = 0;  // rows < first are already part of s
   for (;;) {
     PENGK_STAT_ADD(1, 1);
+    const unsigned long long k2 = PENGK_CLOCK();
     if (bits(s) >= INF_BITS) return s;  // +inf + t = +inf
     const Bases B = bases_of(s);
     float i0 = B.b0, i1 = B.b1;
     mine.run2(i0, i1);
+#ifdef PENGK_SEQSUM_STATS
+    asm volatile("" : "+v"(i0), "+v"(i1));
+#endif
+    const unsigned long long k3 = PENGK_CLOCK();
+    PENGK_STAT_ADD(5, k3 - k2);
     if (lane < first) {
       i0 = B.b0;
       i1 = B.b1;
     }
-    // inclusive prefix inside each row of 16 lanes: (rows l-d .. of the earlier lanes) then (this lane's)
-#define PENGK_ROW_STEP(D)                                                     \
-    {                                                                          \
-      float a0 = row_shr<D>(B.b0, i0), a1 = row_shr<D>(B.b1, i1);              \
-      compose(a0, a1, i0, i1, B);                                              \
-      i0 = a0;                                                                 \
-      i1 = a1;                                                                 \
-    }
-    PENGK_ROW_STEP(1) PENGK_ROW_STEP(2) PENGK_ROW_STEP(4) PENGK_ROW_STEP(8)
-#undef PENGK_ROW_STEP
-    // the rows of 16: totals at lanes 15, 31, 47; what lies in front of rows 1, 2, 3 (wave-uniform)
-    float p0 = lane_value(i0, 15), p1 = lane_value(i1, 15);  // in front of row 1
-    float q0 = p0, q1 = p1;
-    compose(q0, q1, lane_value(i0, 31), lane_value(i1, 31), B);  // in front of row 2
-    float r0 = q0, r1 = q1;
-    compose(r0, r1, lane_value(i0, 47), lane_value(i1, 47), B);  // in front of row 3
-    const uint32_t rw = lane >> 4;
-    float f0 = rw == 1u ? p0 : rw == 2u ? q0 : rw == 3u ? r0 : B.b0;
-    float f1 = rw == 1u ? p1 : rw == 2u ? q1 : rw == 3u ? r1 : B.b1;
-    compose(f0, f1, i0, i1, B);  // rows first .. this lane's
     const uint32_t par = bits(s) & 1u;
-    const float end = s + (par ? f1 - B.b1 : f0 - B.b0);  // the sum behind this lane's row, exact if nothing crossed up to there
+    const uint32_t rw = lane >> 4;
+    float end;  // the sum behind this lane's row, exact if nothing crossed up to there
+    const float d0 = i0 - B.b0, d1 = i1 - B.b1;
+    if (__builtin_amdgcn_ballot_w64(bits(d0) != bits(d1)) == 0ull) {
+      // No row met a tie: both parities take the same increment, and the composition is a prefix SUM of increments --
+      // multiples of u below 2^24 u, so the float additions are exact (or the result is >= 2^(e+1) and gets flagged).
+      float d = d0;
+      d += row_shr<1>(0.0f, d);
+      d += row_shr<2>(0.0f, d);
+      d += row_shr<4>(0.0f, d);
+      d += row_shr<8>(0.0f, d);
+      const float r1 = lane_value(d, 15), r2 = r1 + lane_value(d, 31), r3 = r2 + lane_value(d, 47);
+      d += rw == 1u ? r1 : rw == 2u ? r2 : rw == 3u ? r3 : 0.0f;
+      end = s + d;
+    } else {
+      // inclusive prefix inside each row of 16 lanes: (rows l-d .. of the earlier lanes) then (this lane's)
+#define PENGK_ROW_STEP(D)                                                     \
+      {                                                                        \
+        float a0 = row_shr<D>(B.b0, i0), a1 = row_shr<D>(B.b1, i1);            \
+        compose(a0, a1, i0, i1, B);                                            \
+        i0 = a0;                                                               \
+        i1 = a1;                                                               \
+      }
+      PENGK_ROW_STEP(1) PENGK_ROW_STEP(2) PENGK_ROW_STEP(4) PENGK_ROW_STEP(8)
+#undef PENGK_ROW_STEP
+      // the rows of 16: totals at lanes 15, 31, 47; what lies in front of rows 1, 2, 3 (wave-uniform)
+      float p0 = lane_value(i0, 15), p1 = lane_value(i1, 15);  // in front of row 1
+      float q0 = p0, q1 = p1;
+      compose(q0, q1, lane_value(i0, 31), lane_value(i1, 31), B);  // in front of row 2
+      float r0 = q0, r1 = q1;
+      compose(r0, r1, lane_value(i0, 47), lane_value(i1, 47), B);  // in front of row 3
+      float f0 = rw == 1u ? p0 : rw == 2u ? q0 : rw == 3u ? r0 : B.b0;
+      float f1 = rw == 1u ? p1 : rw == 2u ? q1 : rw == 3u ? r1 : B.b1;
+      compose(f0, f1, i0, i1, B);  // rows first .. this lane's
+      end = s + (par ? f1 - B.b1 : f0 - B.b0);
+    }
     const unsigned long long flagged = __builtin_amdgcn_ballot_w64(bits(end) >= B.limit);
+    const unsigned long long k4 = PENGK_CLOCK();
+    PENGK_STAT_ADD(6, k4 - k3);
     if (!flagged) return lane_value(end, 63);  // the whole block stayed in the binade of s
     const int L = __builtin_ctzll(flagged);
     float v = s;
@@ -171,48 +208,71 @@ __device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, flo
     crossing.read(lds + (uint32_t)L * SEG_STRIDE);
     s = crossing.run1(v);  // the reference's own additions through row L, all lanes alike
     first = (uint32_t)L + 1u;
+#ifdef PENGK_SEQSUM_STATS
+    asm volatile("" : "+v"(s));
+#endif
+    PENGK_STAT_ADD(7, PENGK_CLOCK() - k4);
     if (first == 64u) return s;
   }
 }
 
 // The term source of a chain: load(b, lane, R) fetches block b into 64 registers, deposit(lane, R, lds) spreads them
-// over the LDS rows.  fold_chain overlaps the fetch of blocks b + 1 and b + 2 with the evaluation of block b.
-// CHECK: look at every term; a chain with a negative / non-finite term is summed by the plain loop `serial`.
+// over the LDS rows.
+//
+// Two waves per chain (a workgroup of 128 threads, every thread calls fold_chain): moving a block through a wave --
+// sixteen 16-byte loads, sixteen LDS writes, the wait for them -- takes as long as evaluating it, so wave 1 only
+// fetches (block i into buffer i & 1, the loads of block i + 1 in flight) while wave 0 only evaluates (block i - 1
+// from the other buffer), one workgroup barrier per block.  The result is returned in wave 0 (wave 1 returns 0).
+// CHECK: wave 1 looks at every term; a chain with a negative / non-finite term is summed by the plain loop `serial`.
+constexpr uint32_t CHAIN_THREADS = 128;
+constexpr uint32_t CHAIN_LDS_FLOATS = 2u * LDS_FLOATS + 4u;  // two row buffers + the flag word
 template <class Source, bool CHECK>
-__device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks, float* lds, uint32_t lane) {
-  // two blocks in flight (a block's loads take ~2 us to come back, its evaluation ~0.7 us)
-  float RA[64], RB[64];
-  float s = 0.0f;
-  bool fallback = false;
-  auto step = [&](uint32_t b, float (&R)[64]) {
-    if (CHECK) {
-      uint32_t m = 0;
-#pragma unroll
-      for (int k = 0; k < 64; ++k) m = max(m, bits(R[k]));
-      if (__builtin_amdgcn_ballot_w64(m > 0x7F7FFFFFu)) fallback = true;  // wave-uniform
-    }
-    const unsigned long long c0 = PENGK_CLOCK();
-    src.deposit(lane, R, lds);
-#ifdef PENGK_SEQSUM_STATS
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the clock sees the deposit (and the wait for the block's loads)
-#endif
-    const unsigned long long c1 = PENGK_CLOCK();
-    if (b + 2u < n_blocks) src.load(b + 2u, lane, R);
-    s = fold_block(lds, lane, s);
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long c2 = PENGK_CLOCK();
-    PENGK_STAT_ADD(0, 1);
-    PENGK_STAT_ADD(2, c1 - c0);
-    PENGK_STAT_ADD(3, c2 - c1);
-  };
-  src.load(0u, lane, RA);
-  if (n_blocks > 1u) src.load(1u, lane, RB);
-#pragma unroll 1
-  for (uint32_t b = 0; b < n_blocks && !fallback; b += 2u) {
-    step(b, RA);
-    if (b + 1u < n_blocks && !fallback) step(b + 1u, RB);
+__device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks, float* lds, uint32_t thread) {
+  const uint32_t lane = thread & 63u;
+  const bool fetcher = (uint32_t)__builtin_amdgcn_readfirstlane((int)(thread >> 6)) != 0u;  // wave-uniform
+  volatile uint32_t* bad = reinterpret_cast<volatile uint32_t*>(lds + 2u * LDS_FLOATS);
+  if (CHECK) {
+    if (thread == 0) *bad = 0u;
+    __syncthreads();
   }
-  return fallback ? src.serial() : s;
+  Stats st;
+  float s = 0.0f;
+  if (fetcher) {
+    float R[64];
+    src.load(0u, lane, R);
+#pragma unroll 1
+    for (uint32_t i = 0; i <= n_blocks; ++i) {
+      if (i < n_blocks) {
+        if (CHECK) {
+          uint32_t m = 0;
+#pragma unroll
+          for (int k = 0; k < 64; ++k) m = max(m, bits(R[k]));
+          if (__builtin_amdgcn_ballot_w64(m > 0x7F7FFFFFu) && lane == 0) *bad = 1u;
+        }
+        const unsigned long long c0 = PENGK_CLOCK();
+        src.deposit(lane, R, lds + (i & 1u) * LDS_FLOATS);
+        if (i + 1u < n_blocks) src.load(i + 1u, lane, R);
+        PENGK_STAT_ADD(2, PENGK_CLOCK() - c0);
+      }
+      __syncthreads();
+      if (CHECK && *bad) break;  // (both waves read the flag behind the same barrier)
+    }
+  } else {
+#pragma unroll 1
+    for (uint32_t i = 0; i <= n_blocks; ++i) {
+      if (i > 0u) {
+        const unsigned long long c0 = PENGK_CLOCK();
+        s = fold_block(lds + ((i - 1u) & 1u) * LDS_FLOATS, lane, s, st);
+        PENGK_STAT_ADD(0, 1);
+        PENGK_STAT_ADD(3, PENGK_CLOCK() - c0);
+      }
+      __syncthreads();
+      if (CHECK && *bad) break;
+    }
+    if (CHECK && *bad) s = src.serial();
+  }
+  st.flush(lane);
+  return fetcher ? 0.0f : s;
 }
 
 }  // namespace seqsum

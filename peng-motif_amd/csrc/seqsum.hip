@@ -32,9 +32,9 @@ struct PlainTerms {
   }
 };
 
-__global__ __launch_bounds__(64) void sequential_sum_kernel(const float* __restrict__ terms, uint64_t chain_len,
-                                                            float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float lds[seqsum::LDS_FLOATS];
+__global__ __launch_bounds__(seqsum::CHAIN_THREADS) void sequential_sum_kernel(const float* __restrict__ terms, uint64_t chain_len,
+                                                                                float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float lds[seqsum::CHAIN_LDS_FLOATS];
   const PlainTerms src{terms + (size_t)blockIdx.x * chain_len, chain_len};
   const uint32_t n_blocks = (uint32_t)((chain_len + seqsum::BLOCK - 1) / seqsum::BLOCK);
   const float s = seqsum::fold_chain<PlainTerms, true>(src, n_blocks, lds, threadIdx.x);
@@ -47,7 +47,7 @@ int launch_sequential_sum(pengk_ctx* ctx, const float* d_terms, uint64_t n_chain
   if (n_chains == 0) return PENGK_OK;
   if (n_chains > 0x7FFFFFFFull) return fail(PENGK_ERR_RANGE, "pengk_sequential_sum_f32: %llu chains in one call", (unsigned long long)n_chains);
   if (chain_len > ((uint64_t)1 << 43)) return fail(PENGK_ERR_RANGE, "pengk_sequential_sum_f32: chain of %llu terms", (unsigned long long)chain_len);
-  hipLaunchKernelGGL(sequential_sum_kernel, dim3((unsigned)n_chains), dim3(64), 0, ctx->stream, d_terms, chain_len, d_out);
+  hipLaunchKernelGGL(sequential_sum_kernel, dim3((unsigned)n_chains), dim3(seqsum::CHAIN_THREADS), 0, ctx->stream, d_terms, chain_len, d_out);
   PENGK_HIP(hipGetLastError());
   return PENGK_OK;
 }

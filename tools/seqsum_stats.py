@@ -24,7 +24,7 @@ for i, x in enumerate(seeds):
         pw[i, q, (int(x) >> (2 * q)) & 3] = 0.7
 bg_k = pk.DeviceArray.from_host(ctx, bgprob.to_host()[2])
 ctx.set_option("em_fast", 2)
-st = (C.c_ulonglong * 8)()
+st = (C.c_ulonglong * 12)()
 f = pk.lib().pengk_debug_seqsum_stats
 f.argtypes = [C.c_void_p, C.c_int]
 assert f(st, 1) == 0
@@ -33,5 +33,8 @@ assert f(st, 1) == 0
 blocks, evals, dep, ev = st[0], st[1], st[2], st[3]
 print("blocks %d  evaluations/block %.3f  deposit cycles/block %.0f  evaluation cycles/block %.0f  (s_memtime ticks)" %
       (blocks, evals / blocks, dep / blocks, ev / blocks))
+print("per block (ticks): row read %.0f  additions %.0f/evaluation  prefix %.0f/evaluation  crossing %.0f/crossing" %
+      (st[4] / blocks, st[5] / evals, st[6] / evals, st[7] / max(evals - blocks, 1)))
+print("load issue %.0f ticks/block" % (st[8] / blocks))
 chains = len(seeds) * 4 * W * 10
 print("per chain: %.1f blocks, %.1f extra evaluations (binade crossings)" % (blocks / chains, (evals - blocks) / chains))
