@@ -207,9 +207,9 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  * extra normalisation of the IUPACPattern(ori, pwm) constructor).  Three modes (option "em_fast"):
  *   2  serial: the reference's float32 arithmetic including the ORDER in which it adds the 4^W weights of a PWM
  *      cell (src/peng.cpp:121-127) -- PWMs, iteration counts and `change` are the reference's bit for bit.  From
- *      W = 8 on a cell's chain of roundings is evaluated by one wave as a scan (csrc/seqsum.h; option
- *      "em_serial_scan" = 0 selects the dependent-addition fold, which also takes any PWM with a negative or
- *      non-finite weight).  What a caller needs when discrete decisions follow (motif merging compares similarity
+ *      W = 8 on a cell's chain of roundings is evaluated by a wave as a scan (csrc/seqsum.h; option
+ *      "em_serial_scan" = 0 selects the dependent-addition fold; a PWM with a negative or non-finite weight is
+ *      summed by a plain loop).  What a caller needs when discrete decisions follow (motif merging compares similarity
  *      scores that are exactly tied in real arithmetic for reverse-complement twins); the CLI's default.
  *   0  the reference's float32 terms (three divisions per k-mer weight), summed in fp64 through a fixed tree.
  *   1  (library default) the weight c*s / (1 + s/(prod/bg)) evaluated as c*s*prod / (prod + s*bg) with one

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 // A cell's sum is inherently sequential, but cells and PWMs are independent and the weights are not:
 //   em_weights_kernel    all weights w(x) of a PWM in parallel (reference float operations), to a scratch table;
 //   em_fold_scan_kernel  (W >= 8) one wave per cell evaluates the cell's chain of roundings as a scan (seqsum.h);
-//   em_fold_kernel       (W <= 6, and PWMs with a negative / non-finite weight) one workgroup per position and PWM:
+//   em_fold_kernel       (W <= 6, or option em_serial_scan = 0) one workgroup per position and PWM:
 //                        the four cells (p, a) walk THEIR terms -- the x whose digit p is a, ascending -- from LDS,
 //                        where loader waves stage them with coalesced loads, one dependent addition after the other.
 // ---------------------------------------------------------------------------------------------
@@ -362,13 +362,11 @@ struct FoldGeo {
 
 template <int W>
 __global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
-                                                      double* __restrict__ partials, const uint32_t* __restrict__ bad,
-                                                      int only_bad, uint32_t pwm_stride) {
+                                                      double* __restrict__ partials, uint32_t pwm_stride) {
   using F = FoldGeo<W>;
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int pw = blockIdx.y;
   if (state[2 * pw + 1] == 0) return;
-  if (only_bad && !bad[pw]) return;  // em_fold_scan_kernel summed this PWM
   const uint32_t p = blockIdx.x;  // position
   const uint32_t np = 1u << (2 * W);
   const float* w = wbuf + (size_t)pw * pwm_stride;
@@ -550,20 +548,33 @@ __global__ __launch_bounds__(seqsum::CHAIN_THREADS) void em_fold_scan_kernel(con
 template <int W, int HIMAX>
 __global__ __launch_bounds__(64) void em_finalize_kernel(float* __restrict__ pwms, int32_t* __restrict__ state,
                                                          float* __restrict__ change_out, const double* __restrict__ partials,
-                                                         float threshold, int max_it, uint32_t* __restrict__ bad) {
+                                                         float threshold, int max_it, uint32_t* __restrict__ bad,
+                                                         const float* __restrict__ wbuf, uint32_t pwm_stride) {
   using G = EmGeo<W, HIMAX>;
   const int pw = blockIdx.x;
   if (state[2 * pw + 1] == 0) return;
-  if (bad && threadIdx.x == 0) bad[pw] = 0u;  // serial mode: the next iteration's weights set it again if need be
   __shared__ float s_new[W * 4];
   const int e = threadIdx.x;
+  // serial mode with the scan: a PWM the weights kernel flagged (a negative or non-finite weight -- degenerate inputs
+  // only) was left out by em_fold_scan_kernel; its cells are summed here, one thread per cell, by the plain loop
+  const bool flagged = bad && bad[pw];
   if (e < G::CELLS) {
-    const double* src = partials + (size_t)pw * G::NB * G::CELLS + e;
-    double v = 0.0;
-    for (int b = 0; b < G::NB; ++b) v += src[(size_t)b * G::CELLS];
-    s_new[e] = (float)v;
+    if (flagged) {
+      const float* w = wbuf + (size_t)pw * pwm_stride;
+      const uint32_t p = (uint32_t)e >> 2, a = (uint32_t)e & 3u;
+      float acc = 0.0f;
+      for (uint32_t c = 0; c < (1u << (2 * W - 2)); ++c)
+        acc += w[((c >> (2u * p)) << (2u * p + 2u)) | (a << (2u * p)) | (c & ((1u << (2u * p)) - 1u))];
+      s_new[e] = acc;
+    } else {
+      const double* src = partials + (size_t)pw * G::NB * G::CELLS + e;
+      double v = 0.0;
+      for (int b = 0; b < G::NB; ++b) v += src[(size_t)b * G::CELLS];
+      s_new[e] = (float)v;
+    }
   }
   __syncthreads();
+  if (bad && e == 0) bad[pw] = 0u;  // the next iteration's weights set it again if need be
   if (e == 0) {
     float* old = pwms + (size_t)pw * W * 4;
     float change = 0.0f;
@@ -630,7 +641,7 @@ int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, f
                          ctx->d_em_partials, (int)nb);
       hipLaunchKernelGGL((em_finalize_kernel<W, HIMAX>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
                          d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
-                         (uint32_t*)nullptr);
+                         (uint32_t*)nullptr, (const float*)nullptr, 0u);
     }
     PENGK_HIP(hipGetLastError());
   }
@@ -678,7 +689,8 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   if (rc) return rc;
   uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_em_partials) + flags_at);
   PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)batch * sizeof(uint32_t), ctx->stream));
-  // cells of at least four blocks are summed by the scan (seqsum.h); the dependent-addition fold takes the short
+  // cells of at least four blocks are summed by the scan (seqsum.h; flagged PWMs by the finalize kernel's plain loop);
+  // the dependent-addition fold takes the short
   // chains of W <= 6 and any PWM whose weights the scan cannot take
   const unsigned wb = (unsigned)std::min<size_t>((np + 255) / 256, 1024);
   for (int64_t first = 0; first < n_pwm; first += batch) {
@@ -690,16 +702,20 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
       else
         hipLaunchKernelGGL((em_weights_kernel<W, false>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
                            d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
+      bool scanned = false;
       if constexpr (SCAN) {
-        if (scan)
+        if (scan) {
           hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(seqsum::CHAIN_THREADS), 0, ctx->stream,
                              d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad, (uint32_t)nb);
+          scanned = true;
+        }
       }
-      hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,
-                         ctx->d_em_tables, ctx->d_em_partials, bad, scan ? 1 : 0, (uint32_t)pwm_stride);
+      if (!scanned)
+        hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,
+                           ctx->d_em_tables, ctx->d_em_partials, (uint32_t)pwm_stride);
       hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
                          d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
-                         bad);
+                         scanned ? bad : (uint32_t*)nullptr, (const float*)ctx->d_em_tables, (uint32_t)pwm_stride);
     }
     PENGK_HIP(hipGetLastError());
   }

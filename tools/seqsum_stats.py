@@ -31,10 +31,9 @@ assert f(st, 1) == 0
 ctx.em(W, pw, counts, bg_k, 1e4, 0.0, 10)
 assert f(st, 1) == 0
 blocks, evals, dep, ev = st[0], st[1], st[2], st[3]
-print("blocks %d  evaluations/block %.3f  deposit cycles/block %.0f  evaluation cycles/block %.0f  (s_memtime ticks)" %
+print("blocks %d  evaluations/block %.3f  fetch wave: deposit + next block's loads, cycles/block %.0f  evaluation cycles/block %.0f  (s_memtime ticks)" %
       (blocks, evals / blocks, dep / blocks, ev / blocks))
 print("per block (ticks): row read %.0f  additions %.0f/evaluation  prefix %.0f/evaluation  crossing %.0f/crossing" %
       (st[4] / blocks, st[5] / evals, st[6] / evals, st[7] / max(evals - blocks, 1)))
-print("load issue %.0f ticks/block" % (st[8] / blocks))
 chains = len(seeds) * 4 * W * 10
 print("per chain: %.1f blocks, %.1f extra evaluations (binade crossings)" % (blocks / chains, (evals - blocks) / chains))
