@@ -689,9 +689,8 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   if (rc) return rc;
   uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_em_partials) + flags_at);
   PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)batch * sizeof(uint32_t), ctx->stream));
-  // cells of at least four blocks are summed by the scan (seqsum.h; flagged PWMs by the finalize kernel's plain loop);
-  // the dependent-addition fold takes the short
-  // chains of W <= 6 and any PWM whose weights the scan cannot take
+  // cells of at least four blocks are summed by the scan (seqsum.h; flagged PWMs by the finalize kernel's plain loop),
+  // the short chains of W <= 6 by the dependent-addition fold
   const unsigned wb = (unsigned)std::min<size_t>((np + 255) / 256, 1024);
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
