@@ -363,7 +363,7 @@ def main():
         alg_bytes = (nseq * L + 3) // 4 + 8 * int(ni.value) + 4 * NP
         achieved = alg_bytes / (count_ms * 1e-3) / 1e9 if count_ms > 0 else 0.0
         mode_name = {0: "reference terms, fp64 tree sums (1e-5 rel.)", 1: "one reciprocal per weight, fp64 tree sums (1e-5 rel., BASELINE.json's bar)",
-                     2: "serial float32 in the reference's order, bit-exact (the peng_motif CLI's mode)"}
+                     2: "serial float32 in the reference's order, bit-exact (the peng_motif CLI's mode); every cell's chain of roundings evaluated as a wave-wide scan (csrc/seqsum.h)"}
         step_other_ms = (ms_per_step - em_ms + em_other_ms) if em_other_ms is not None else None
         out = {
             "metric": "4^W pattern z-scores/s + EM PWM-kmer evals/s at W=10; Gbp/s k-mer count",

@@ -139,3 +139,33 @@ def test_config4_em_stress_1000_top_count_seeds_plus_table(ctx):
     # float32 additions per cell over 1.9e9 counted windows leave up to ~1e-3 absolute on a PWM entry here (SURVEY.md A.7
     # measured 1.9e-5 on a 1M-sequence set) -- the fp64-tree mode is the more accurate of the two.
     assert np.abs(ser.astype(np.float64) - got).max() <= 3e-3
+
+
+def test_serial_em_at_w12_bit_exact_against_oracle(ctx):
+    """The serial mode at W = 12: 48 cells of 4^11 = 4.2M weights each (1024 blocks of the scan per cell), three PWMs,
+    three iterations, against the oracle's left-to-right float32 sums -- bit for bit, on the count table of a 100k-sequence
+    synthetic set (most of the 16.7M k-mers have count 0: long stretches of zero terms in every cell)."""
+    W, L, n, K = 12, 200, 100_000, 2
+    ctx.synth(1, 0, n, L, W)
+    counts, ltot, bg = ctx.count_bg(True)
+    ctx.mirror(W, counts)
+    V = ctx.bg_model(bg, K)
+    bgprob, expected, logp, z = ctx.pattern_stats(W, True, K, K, V, ltot, counts)
+    c_host = counts.to_host()
+    bgk_host = bgprob.to_host()[K]
+    seeds = _top_seeds(c_host, 3)
+    pw0 = _seed_pwms(seeds, W)
+    rng = np.random.default_rng(12)
+    pw0[2] = rng.dirichlet(np.ones(4), size=W).astype(np.float32)
+    bg_k = pk.DeviceArray.from_host(ctx, bgk_host)
+    ctx.set_option("em_fast", 2)
+    try:
+        got, iters, change = ctx.em(W, pw0, counts, bg_k, 1e4, 0.0, 3)
+    finally:
+        ctx.set_option("em_fast", 1)
+    c64 = c_host.astype(np.uint64)
+    for i in range(3):
+        ref, it, ch = po.em(W, c64, bgk_host, pw0[i], 1e4, 0.0, 3, mode=0, final_norm=False)
+        assert iters[i] == it == 3
+        assert got[i].tobytes() == ref.astype(np.float32).tobytes(), i
+        assert np.float32(change[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
