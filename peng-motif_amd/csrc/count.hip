@@ -397,6 +397,7 @@ struct KeySplit {
   __host__ __device__ static inline uint32_t join(uint32_t b, uint32_t p, uint32_t /*outer*/ = 0) {
     return (p & LOW) | (b << S) | ((p >> S) << (S + NBITS));
   }
+  __host__ __device__ static inline bool valid(uint32_t p) { return p != KEY_INVALID; }
 };
 
 // W = 12 (24-bit ids) needs 2^9 buckets of 2^15 bins: two levels.
@@ -407,7 +408,9 @@ struct Split12L1 {
   static constexpr uint32_t NB = 32;
   __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> 8) & 31u; }
   __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & 0xFFu) | ((id >> 13) << 8); }
-  __host__ __device__ static inline uint32_t join(uint32_t b1, uint32_t p1) { return (p1 & 0xFFu) | (b1 << 8) | ((p1 >> 8) << 13); }
+  __host__ __device__ static inline uint32_t join(uint32_t b1, uint32_t p1, uint32_t /*outer*/ = 0) { return (p1 & 0xFFu) | (b1 << 8) | ((p1 >> 8) << 13); }
+  // a 19-bit payload; INVALID_ID and padding entries carry higher bits (and travel on as KEY_INVALID through level 2)
+  __host__ __device__ static inline bool valid(uint32_t p1) { return p1 < (1u << 19); }
 };
 struct Split12L2 {
   static constexpr int NBITS = 4;
@@ -419,27 +422,30 @@ struct Split12L2 {
     const uint32_t p1 = (p2 & 0xFFu) | (b2 << 8) | ((p2 >> 8) << 12);
     return Split12L1::join(outer, p1);
   }
+  __host__ __device__ static inline bool valid(uint32_t p2) { return p2 != KEY_INVALID; }
 };
 
 // One row per (wave, bucket): the ring and, behind it, its counter.  The odd row stride (65 dwords) spreads rows over
 // the LDS banks: rings fill at the same pace, and with a 256-byte stride equal fill levels would put every lane of
 // the 16-bit ring write -- and every counter -- on the same few banks.
-struct ScatterRow {
-  uint16_t ring[RING_CAP];
+template <class E>  // E = uint16_t (15-bit payloads) or uint32_t (the 19-bit payloads of W = 12's first level)
+struct ScatterRowT {
+  E ring[RING_CAP];
   uint32_t fill4;  // 4 x (keys ever appended to this (wave, bucket))
 };
-template <int NBITS, int WPW>
+typedef ScatterRowT<uint16_t> ScatterRow;
+template <int NBITS, int WPW, class E = uint16_t>
 struct ScatterShared {
   static constexpr int NB = 1 << NBITS;
-  ScatterRow row[WPW][NB];
+  ScatterRowT<E> row[WPW][NB];
 };
 
 // The one LDS instance per workgroup.  It is reached through this accessor, never through a pointer
 // stored in a struct: a generic pointer made the compiler emit flat_load for the ring reads, and a flat
 // access waits for vmcnt(0) -- i.e. for every key store still in flight -- on every flush.
-template <int NBITS, int WPW>
-__device__ __forceinline__ ScatterShared<NBITS, WPW>& scatter_lds() {
-  __shared__ ScatterShared<NBITS, WPW> sh;
+template <int NBITS, int WPW, class E = uint16_t>
+__device__ __forceinline__ ScatterShared<NBITS, WPW, E>& scatter_lds() {
+  __shared__ ScatterShared<NBITS, WPW, E> sh;
   return sh;
 }
 
@@ -454,44 +460,48 @@ __device__ __forceinline__ ScatterShared<NBITS, WPW>& scatter_lds() {
 // a group" is ONE sub-dword compare, and (value >> 1) & 0xFF is the byte offset of the key's ring entry.  A
 // suppressed window arrives as INVALID_ID: its bucket bits select the last bucket and its payload bits are
 // KEY_INVALID, which pass B skips -- no select, no sink row (7 vector instructions per key instead of 14).
-template <class KS, int NBITS, int WPW = 4>
+template <class KS, int NBITS, int WPW = 4, class E = uint16_t>
 struct ScatterEmit {
   static constexpr int NB = 1 << NBITS;
-  static_assert(GROUP == 64, "a group is one 2-byte store per lane");
+  static constexpr uint32_t ES = (uint32_t)sizeof(E);           // bytes per ring / slice entry
+  static constexpr uint32_t ESH = ES == 2u ? 1u : 2u;            // log2(ES)
+  static constexpr uint32_t PAD = ES == 2u ? KEY_INVALID : 0xFFFFFFFFu;  // an entry pass B / the next level skips
+  typedef ScatterRowT<E> Row;
+  static_assert(GROUP == 64, "a group is one entry per lane");
   static_assert(RING_CAP == 128, "byte 0 of the counter addresses the ring");
-  uint16_t* __restrict__ keys;
-  uint32_t slice_cap;  // entries per (wave, bucket) slice, multiple of 64; NB * slice_cap < 2^32
+  E* __restrict__ keys;
+  uint32_t slice_cap;  // entries per (wave, bucket) slice, multiple of 64; NB * slice_cap * ES < 2^32
   uint32_t* __restrict__ slice_fill;  // [n_waves][NB] entries written (multiple of 64)
   uint32_t* __restrict__ hist;
   uint32_t wave, lane, wave_global;   // wave, wave_global: wave-uniform (readfirstlane'd by the caller)
   uint32_t outer;     // level-1 bucket these keys came from (two-level partition); 0 otherwise
 
-  // All threads of the workgroup, before the first barrier: rings KEY_INVALID, counters 0.
+  // All threads of the workgroup, before the first barrier: rings all ones, counters 0.
   static __device__ __forceinline__ void init_lds() {
-    ScatterShared<NBITS, WPW>& sh = scatter_lds<NBITS, WPW>();
-    static_assert(sizeof(ScatterRow) == 2 * RING_CAP + 4, "row = ring + counter");
+    ScatterShared<NBITS, WPW, E>& sh = scatter_lds<NBITS, WPW, E>();
+    static_assert(sizeof(Row) == ES * RING_CAP + 4, "row = ring + counter");
     uint32_t* w = reinterpret_cast<uint32_t*>(&sh.row[0][0]);
-    for (uint32_t i = threadIdx.x; i < (uint32_t)WPW * NB * (sizeof(ScatterRow) / 4u); i += blockDim.x)
-      w[i] = (i % (uint32_t)(sizeof(ScatterRow) / 4u)) == (uint32_t)(RING_CAP / 2) ? 0u : 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)WPW * NB * (sizeof(Row) / 4u); i += blockDim.x)
+      w[i] = (i % (uint32_t)(sizeof(Row) / 4u)) == (uint32_t)(ES * RING_CAP / 4u) ? 0u : 0xFFFFFFFFu;
   }
 
   typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-  typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
-  typedef __attribute__((address_space(1))) uint16_t global_u16_t;
+  typedef __attribute__((address_space(3))) E lds_e_t;
+  typedef __attribute__((address_space(1))) E global_e_t;
 
   // A completed group (64 ring entries from slot g0, a multiple of 64) goes to slice entries [g0, g0 + 64) as ONE
-  // 128-byte line, one 2-byte load and store per lane.  Everything wave-uniform about a group -- where it starts in
-  // the ring, where it goes in the wave's key region, whether the slice still has room -- is computed by the lane whose
-  // key completed it, with a handful of vector instructions that all lanes run side by side; the loop then needs two
-  // v_readlane per group and no scalar multiply / shift / mask chain (13 instruction issues per group instead of 30;
-  // the flush was half of what this kernel issues).
+  // line (128 bytes of 16-bit entries, 256 of 32-bit ones), one load and store per lane.  Everything wave-uniform about
+  // a group -- where it starts in the ring, where it goes in the wave's key region, whether the slice still has room --
+  // is computed by the lane whose key completed it, with a handful of vector instructions that all lanes run side by
+  // side; the loop then needs two v_readlane per group and no scalar multiply / shift / mask chain (13 instruction
+  // issues per group instead of 30; the flush was half of what this kernel issues).
   __device__ __forceinline__ void flush_triggered(unsigned long long trig, uint32_t row, uint32_t b, uint32_t s4) {
     // (an empty asm: the compiler must not fold the caller's wave-uniform "some key completed a group" branch into the
     // masks below -- that turns one scalar branch per key into five scalar instructions)
     asm volatile("");
     const uint32_t g4 = s4 - 4u * (uint32_t)(GROUP - 1);        // 4 x first slot of the group (in trigger lanes)
-    const uint32_t src = row + ((g4 >> 1) & (uint32_t)RING_CAP);  // ring byte offset 0 or 128
-    const uint32_t dst = b * (2u * slice_cap) + (g4 >> 1);        // byte offset in the wave's region; NB * cap < 2^31
+    const uint32_t src = row + ((g4 >> (2u - ESH)) & (ES * (uint32_t)GROUP));  // ring byte offset: first or second half
+    const uint32_t dst = b * (ES * slice_cap) + (g4 >> (2u - ESH));  // byte offset in the wave's region
     const unsigned long long fits = __builtin_amdgcn_ballot_w64(g4 + 4u * GROUP <= 4u * slice_cap);
     unsigned long long todo = trig & fits;
     unsigned long long over = trig & ~fits;
@@ -503,18 +513,18 @@ struct ScatterEmit {
       // A plain LDS load (a volatile one makes the compiler drain lgkmcnt(0) in front of it).  The LDS executes a wave's
       // operations in order, so it sees every ring write issued before it; ring writes through integer-formed addresses
       // lie between two reads of a location, so it cannot be satisfied from an older copy.
-      uint32_t v = *(lds_u16_t*)(uintptr_t)(s_src + 2u * lane);
+      uint32_t v = *(lds_e_t*)(uintptr_t)(s_src + ES * lane);
       asm volatile("" : "+v"(v));  // consumed here on every path: no wait for it leaks into the next window's code
-      global_u16_t* out = (global_u16_t*)((char*)region + s_dst);
-      __builtin_nontemporal_store((uint16_t)v, &out[lane]);  // written once, read once by pass B
+      global_e_t* out = (global_e_t*)((char*)region + s_dst);
+      __builtin_nontemporal_store((E)v, &out[lane]);  // written once, read once by the next pass
     }
     while (over) {  // slice full: count these windows directly (rare; skewed inputs)
       const int p = __builtin_ctzll(over);
       over &= over - 1;
       const uint32_t s_src = (uint32_t)__builtin_amdgcn_readlane((int)src, p);
       const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)b, p);
-      const uint32_t v = *(lds_u16_t*)(uintptr_t)(s_src + 2u * lane);
-      if (v != KEY_INVALID) __hip_atomic_fetch_add(&hist[KS::join(fb, v, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t v = *(lds_e_t*)(uintptr_t)(s_src + ES * lane);
+      if (KS::valid(v)) __hip_atomic_fetch_add(&hist[KS::join(fb, v, outer)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -523,18 +533,18 @@ struct ScatterEmit {
   // compiler otherwise re-materialises the scalar base with a v_mov per key).
   uint32_t rowbase = 0;
   __device__ __forceinline__ void bind() {
-    rowbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&scatter_lds<NBITS, WPW>().row[wave][0];
+    rowbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&scatter_lds<NBITS, WPW, E>().row[wave][0];
     asm volatile("" : "+v"(rowbase));
     region = keys + (size_t)wave_global * NB * slice_cap;
   }
-  uint16_t* region = nullptr;  // this wave's key region (wave-uniform): NB slices of slice_cap entries
+  E* region = nullptr;  // this wave's key region (wave-uniform): NB slices of slice_cap entries
 
   // append one key per lane: the row of its bucket (returned through `row`) and 4 x its slot
   __device__ __forceinline__ uint32_t append(uint32_t b, uint32_t key, uint32_t& row) const {
-    row = b * (uint32_t)sizeof(ScatterRow) + rowbase;  // b < NB: one v_mad_u32_u24
-    const uint32_t s4 = __hip_atomic_fetch_add((lds_u32_t*)(uintptr_t)(row + 2u * RING_CAP), 4u, __ATOMIC_RELAXED,
+    row = b * (uint32_t)sizeof(Row) + rowbase;  // b < NB: one v_mad_u32_u24
+    const uint32_t s4 = __hip_atomic_fetch_add((lds_u32_t*)(uintptr_t)(row + ES * RING_CAP), 4u, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-    *(lds_u16_t*)(uintptr_t)(row + ((s4 >> 1) & 0xFFu)) = (uint16_t)KS::payload(key);
+    *(lds_e_t*)(uintptr_t)(row + ((s4 >> (2u - ESH)) & (ES * RING_CAP - 1u))) = (E)KS::payload(key);
     return s4;
   }
 
@@ -556,18 +566,19 @@ struct ScatterEmit {
     if (trig) flush_triggered(trig, row, b, s4);
   }
 
-  // end of kernel: lane b pads bucket b's last, partial group with KEY_INVALID -- appending the padding, so that the
-  // group is complete and leaves like every other -- and publishes how much of the slice is filled
+  // end of kernel: lane b pads bucket b's last, partial group with all-ones entries -- appending the padding, so that
+  // the group is complete and leaves like every other -- and publishes how much of the slice is filled
   __device__ __forceinline__ void drain() {
     __builtin_amdgcn_wave_barrier();
     uint32_t row = 0, s4_last = 0;
     bool padded = false;
     if (lane < (uint32_t)NB) {
-      row = lane * (uint32_t)sizeof(ScatterRow) + rowbase;
-      const uint32_t c4 = __hip_atomic_load((lds_u32_t*)(uintptr_t)(row + 2u * RING_CAP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      row = lane * (uint32_t)sizeof(Row) + rowbase;
+      const uint32_t c4 = __hip_atomic_load((lds_u32_t*)(uintptr_t)(row + ES * RING_CAP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       const uint32_t r = (c4 >> 2) & (uint32_t)(GROUP - 1);
       if (r) {
-        for (uint32_t i = r; i < (uint32_t)GROUP; ++i) *(lds_u16_t*)(uintptr_t)(row + (((c4 >> 1) & 0xFFu) + 2u * (i - r))) = (uint16_t)KEY_INVALID;
+        for (uint32_t i = r; i < (uint32_t)GROUP; ++i)
+          *(lds_e_t*)(uintptr_t)(row + (((c4 >> (2u - ESH)) & (ES * RING_CAP - 1u)) + ES * (i - r))) = (E)PAD;
         s4_last = c4 + 4u * ((uint32_t)GROUP - r) - 4u;  // the slot value the completing key would have got
         padded = true;
       }
@@ -605,114 +616,26 @@ __global__ __launch_bounds__(64 * SCATTER_WPW) void count_scatter_kernel(const u
 }
 
 // ---- two-level partition (W = 12) -----------------------------------------------------------------------
-// Level 1: same scan; 32-bit keys (19-bit payload1) into 32 wave-private rings of 64 entries; a ring that
-// completes 32 entries leaves as one 128-byte line (32 lanes x dword) into region1[wave][bucket1][cap1].
-constexpr int RING32_CAP = 64;
-constexpr int GROUP32 = 32;
-constexpr uint32_t KEY32_INVALID = 0xFFFFFFFFu;
-
-struct Scatter32Shared {
-  uint32_t ring[4][33][RING32_CAP];
-  uint32_t fill[4][33];
-};
-__device__ __forceinline__ Scatter32Shared& scatter32_lds() {
-  __shared__ Scatter32Shared sh;
-  return sh;
-}
-
-// Same cursor-free scheme as ScatterEmit: the ring counter's return value is the key's position in the slice.
-// Counter b starts at b (bank spread; < GROUP32), the skipped entries are KEY32_INVALID padding.
-struct Scatter32Emit {
-  typedef __attribute__((address_space(1))) uint32_t global_u32;
-  uint32_t* __restrict__ keys;
-  uint32_t slice_cap;  // entries per (wave, bucket1) slice, multiple of GROUP32; 32 * slice_cap < 2^32
-  uint32_t* __restrict__ slice_fill;
-  uint32_t* __restrict__ hist;
-  uint32_t wave, lane, wave_global;  // wave, wave_global: wave-uniform
-
-  static __device__ __forceinline__ void init_lds() {
-    Scatter32Shared& sh = scatter32_lds();
-    for (uint32_t i = threadIdx.x; i < 4u * 33u * RING32_CAP; i += blockDim.x) (&sh.ring[0][0][0])[i] = KEY32_INVALID;
-    for (uint32_t i = threadIdx.x; i < 4u * 33u; i += blockDim.x) {
-      const uint32_t b = i % 33u;
-      (&sh.fill[0][0])[i] = b < 32u ? b : 0u;
-    }
-  }
-
-  // group of 32 ring entries from slot g0 (a multiple of 32) -> slice entries [g0, g0 + 32): one 128-byte line
-  __device__ __forceinline__ void flush_group(uint32_t b, uint32_t g0, uint32_t nvalid) {
-    typedef const volatile __attribute__((address_space(3))) uint32_t lds_u32;
-    lds_u32* ring = (lds_u32*)&scatter32_lds().ring[wave][b][0];
-    uint32_t v = ring[(g0 & (uint32_t)(RING32_CAP - 1)) + (lane & 31u)];
-    if ((lane & 31u) >= nvalid) v = KEY32_INVALID;
-    if (g0 + (uint32_t)GROUP32 <= slice_cap) {  // wave-uniform
-      global_u32* dst = (global_u32*)(keys + ((size_t)wave_global * 32u * slice_cap + (size_t)(b * slice_cap + g0)));
-      if (lane < 32u) __builtin_nontemporal_store(v, &dst[lane]);
-    } else if (lane < 32u && v != KEY32_INVALID) {  // slice full: count directly
-      __hip_atomic_fetch_add(&hist[Split12L1::join(b, v)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-
-  // A ring holds RING32_CAP = 64 entries and leaves in groups of 32, so at most 31 unflushed keys wait in it.
-  // The wave appends in two half-waves (lanes 0-31, flush what completed, lanes 32-63): a single call can then add
-  // at most 32 keys to one ring before the next flush, 31 + 32 < 64, and no unflushed entry is ever overwritten --
-  // even when all 64 lanes of a step hit one bucket (adjacent identical sequences, poly-T on the plus strand).
-  static_assert(RING32_CAP >= GROUP32 - 1 + 32 + 1, "a half-wave append must fit behind the unflushed rest");
-  __device__ __forceinline__ void full(uint32_t key) { masked(key, key != INVALID_ID); }
-  __device__ __forceinline__ void masked(uint32_t can, bool active) {
-    const uint32_t b = active ? Split12L1::bucket(can) : 32u;  // inactive lanes: sink bucket, never flushed
-    const uint32_t payload = Split12L1::payload(can);
-    Scatter32Shared& sh = scatter32_lds();
-    static_assert(RING32_CAP == 64, "ring rows are 64 entries");
-#pragma unroll
-    for (uint32_t half = 0; half < 2u; ++half) {
-      const bool mine = (lane >> 5) == half;
-      uint32_t slot = 0;
-      if (mine) {
-        slot = atomicAdd(&sh.fill[wave][b], 1u);
-        (&sh.ring[wave][0][0])[(b << 6) | (slot & (uint32_t)(RING32_CAP - 1))] = payload;
-      }
-      unsigned long long trig = __builtin_amdgcn_ballot_w64(mine && (slot & (uint32_t)(GROUP32 - 1)) == (uint32_t)(GROUP32 - 1));
-      while (trig) {
-        const int src = __builtin_ctzll(trig);
-        trig &= trig - 1;
-        const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);
-        const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)slot, src);
-        if (fb == 32u) continue;
-        __builtin_amdgcn_wave_barrier();
-        flush_group(fb, fs - (uint32_t)(GROUP32 - 1), (uint32_t)GROUP32);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-
-  __device__ __forceinline__ void drain() {
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t b = 0; b < 32u; ++b) {
-      const uint32_t f = __hip_atomic_load(&scatter32_lds().fill[wave][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      const uint32_t r = f & (uint32_t)(GROUP32 - 1);
-      if (r) flush_group(b, f & ~(uint32_t)(GROUP32 - 1), r);
-    }
-    if (lane < 32u) {
-      const uint32_t f = __hip_atomic_load(&scatter32_lds().fill[wave][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      const uint32_t full = (f + (uint32_t)(GROUP32 - 1)) & ~(uint32_t)(GROUP32 - 1);
-      slice_fill[(size_t)wave_global * 32u + lane] = full < slice_cap ? full : slice_cap;
-    }
-  }
-};
+// Level 1: same scan, same emitter with 32-bit ring entries (19-bit payload1): 32 wave-private rings of 128 entries,
+// a group of 64 leaves as one 256-byte line into region1[wave][bucket1][cap1].  16.5 KiB of rings per wave: three
+// waves per workgroup, three workgroups per CU.  (Round 1's level 1 appended in two half-waves per window into
+// 64-entry rings, with range tests and a sink bucket: 6.1 ms for a 12.5M-sequence shard.)
+constexpr int SCATTER12_WPW = 3;
+typedef ScatterEmit<Split12L1, 5, SCATTER12_WPW, uint32_t> Scatter12Emit;
 
 template <bool BOTH, bool BG>
-__global__ __launch_bounds__(256) void count_scatter12_kernel(const uint32_t* __restrict__ words32,
+__global__ __launch_bounds__(64 * SCATTER12_WPW) void count_scatter12_kernel(const uint32_t* __restrict__ words32,
                                                               const uint64_t* __restrict__ items, uint32_t n_items,
                                                               uint32_t* __restrict__ keys, uint32_t slice_cap,
                                                               uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
                                                               unsigned long long* __restrict__ ltot,
                                                               uint32_t* __restrict__ defer, uint32_t* __restrict__ bg_partials) {
-  Scatter32Emit::init_lds();
+  Scatter12Emit::init_lds();
   bg_begin<BG>();
   __syncthreads();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  Scatter32Emit e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * 4u + wave};
+  Scatter12Emit e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * (uint32_t)SCATTER12_WPW + wave, 0u};
+  e.bind();
   scan_items<12, BOTH, BG>(words32, items, n_items, ltot, defer, e);
   e.drain();
   bg_end<BG>(bg_partials);
@@ -734,15 +657,16 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
   const uint32_t per = (n_slices1 + bpb1 - 1) / bpb1;
   const uint32_t first = j * per, last = min(n_slices1, first + per);
   for (uint32_t s = first + wave; s < last; s += 4) {
-    const uint32_t n = fill1[(size_t)s * 32u + b1];  // multiple of GROUP32
+    const uint32_t n = fill1[(size_t)s * 32u + b1];  // multiple of GROUP
     const uint32_t* src = keys1 + ((size_t)s * 32u + b1) * cap1;
     // 256 keys per step: one 16-byte load per lane, the next step's already in flight while these four are appended
-    // (one key per lane and step left the wave waiting for every line it asked for).  Padding keys (KEY32_INVALID) need
-    // no test: their bucket bits select the last bucket and their payload bits are KEY_INVALID, which pass B skips.
+    // (one key per lane and step left the wave waiting for every line it asked for).  Padding and suppressed-window
+    // entries (bits above the 19-bit payload set) need no test: their bucket bits select the last bucket and their
+    // payload bits are KEY_INVALID, which pass B skips.
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const u4 pad = {KEY32_INVALID, KEY32_INVALID, KEY32_INVALID, KEY32_INVALID};
+    const u4 pad = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     const u4* src4 = reinterpret_cast<const u4*>(src);  // slices start on multiples of cap1 (a multiple of 32 entries)
-    const uint32_t n4 = n / 4u;                         // n is a multiple of GROUP32
+    const uint32_t n4 = n / 4u;                         // n is a multiple of GROUP
     u4 nxt = lane < n4 ? __builtin_nontemporal_load(&src4[lane]) : pad;
     for (uint32_t i = 0; i < n4; i += 64) {  // wave-uniform trip count
       const u4 k = nxt;
@@ -1208,10 +1132,12 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
 int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items, uint64_t* d_bg) {
   const uint32_t np = 1u << 24;
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
-  const uint32_t blocks_needed = (n_items + 255) / 256;
-  const uint32_t max_blocks = (uint32_t)ctx->num_cu * 4u;
+  constexpr uint32_t TPB1 = 64u * SCATTER12_WPW;
+  const uint32_t blocks_needed = (n_items + TPB1 - 1) / TPB1;
+  constexpr uint32_t lds_per_wg1 = (uint32_t)(sizeof(ScatterShared<5, SCATTER12_WPW, uint32_t>) + sizeof(BgLds) + 511u) & ~511u;
+  const uint32_t max_blocks = (uint32_t)ctx->num_cu * ((160u * 1024u) / lds_per_wg1);
   const uint32_t blocks1 = blocks_needed < max_blocks ? blocks_needed : max_blocks;
-  const uint32_t n_waves1 = blocks1 * 4u;
+  const uint32_t n_waves1 = blocks1 * (uint32_t)SCATTER12_WPW;
   const uint64_t windows = ctx->n_windows_hint ? ctx->n_windows_hint : ctx->n_items * (uint64_t)ctx->item_windows;
   // level-1 slices
   uint64_t share1 = windows / (32ull * n_waves1);
@@ -1228,7 +1154,8 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   uint64_t cap2_64 = share2 + share2 / 2 + 512;
   if (ctx->key_cap_override) cap2_64 = ctx->key_cap_override;
   cap2_64 = (cap2_64 + 63) / 64 * 64;
-  if (cap1_64 * 32ull >= (1ull << 32) || cap2_64 * 16ull >= (1ull << 31)) return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
+  if (cap1_64 * 32ull >= (1ull << 30) || cap2_64 * 16ull >= (1ull << 31)) return fail(  // 32-bit byte offsets inside a wave's slices
+      PENGK_ERR_RANGE, "shard too large for the partitioned count");
   const uint32_t cap1 = (uint32_t)cap1_64, cap2 = (uint32_t)cap2_64;
   const size_t bytes1 = (size_t)n_waves1 * 32u * cap1 * sizeof(uint32_t);
   const size_t bytes2 = (size_t)n_waves2 * 16u * cap2 * sizeof(uint16_t);
@@ -1251,7 +1178,7 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
     if (rc) return rc;
   }
 #define TA_S12(B, G) B, G
-  PENGK_LAUNCH_BB(count_scatter12_kernel, TA_S12, both, d_bg != nullptr, dim3(blocks1), dim3(256), w32, ctx->d_items, n_items, keys1,
+  PENGK_LAUNCH_BB(count_scatter12_kernel, TA_S12, both, d_bg != nullptr, dim3(blocks1), dim3(TPB1), w32, ctx->d_items, n_items, keys1,
                   cap1, fill1, d_counts, lt, ctx->d_defer, bgp);
 #undef TA_S12
   PENGK_HIP(hipGetLastError());
