@@ -493,28 +493,36 @@ struct EmTerms {
 #pragma unroll
     for (uint32_t k = 0; k < 16u; ++k) g[k] = 4u * x_of(256u * k + 4u * lane);
   }
-  __device__ __forceinline__ void load(uint32_t b, uint32_t lane, float (&R)[64]) const {
+  // share `part` of NF: the loads k = part * 16 / NF .. of the block (part is wave-uniform; the selects below pick the
+  // share's offsets once per call)
+  template <uint32_t NF>
+  __device__ __forceinline__ void load(uint32_t b, uint32_t part, uint32_t lane, float (&R)[64 / NF]) const {
     // wave-uniform (readfirstlane: the base stays in scalar registers, the load takes it plus a 32-bit lane offset)
     const uint32_t F = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x_of(b * seqsum::BLOCK) - (a << (2u * p))));
     const char* base = reinterpret_cast<const char*>(w + F);
 #pragma unroll
-    for (uint32_t k = 0; k < 16u; ++k) {
-      const f4 v = *reinterpret_cast<const f4*>(base + g[k]);
+    for (uint32_t k = 0; k < 16u / NF; ++k) {
+      uint32_t off = g[k];
+#pragma unroll
+      for (uint32_t q = 1; q < NF; ++q) off = part == q ? g[q * (16u / NF) + k] : off;
+      const f4 v = *reinterpret_cast<const f4*>(base + off);
       R[4u * k] = v.x;
       R[4u * k + 1u] = v.y;
       R[4u * k + 2u] = v.z;
       R[4u * k + 3u] = v.w;
     }
   }
-  __device__ __forceinline__ void deposit(uint32_t lane, const float (&R)[64], float* lds) const {
+  template <uint32_t NF>
+  __device__ __forceinline__ void deposit(uint32_t part, uint32_t lane, const float (&R)[64 / NF], float* lds) const {
+    float* dst = lds + (4u * (16u / NF) * part + (lane >> 4)) * seqsum::SEG_STRIDE + 4u * (lane & 15u);
 #pragma unroll
-    for (uint32_t k = 0; k < 16u; ++k) {
+    for (uint32_t k = 0; k < 16u / NF; ++k) {
       f4 v;
       v.x = R[4u * k];
       v.y = R[4u * k + 1u];
       v.z = R[4u * k + 2u];
       v.w = R[4u * k + 3u];
-      *reinterpret_cast<f4*>(lds + (4u * k + (lane >> 4)) * seqsum::SEG_STRIDE + 4u * (lane & 15u)) = v;
+      *reinterpret_cast<f4*>(dst + 4u * k * seqsum::SEG_STRIDE) = v;
     }
   }
   __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)

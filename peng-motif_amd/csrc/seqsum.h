@@ -138,13 +138,15 @@ __device__ __forceinline__ float lane_value(float v, int l) {  // wave-uniform
 // left the binade up to there.  No lane flagged: lane 63 holds the result.  Otherwise the first flagged row is added
 // the reference's way and the rows behind it are evaluated again in the new binade.
 __device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, float s, Stats& st) {
-  const unsigned long long k0 = PENGK_CLOCK();
-  Row mine;
-  mine.read(lds + lane * SEG_STRIDE);
-  const unsigned long long k1 = PENGK_CLOCK();
-  PENGK_STAT_ADD(4, k1 - k0);
   uint32_t first = 0;  // rows < first are already part of s
   for (;;) {
+    // (the row is read again after a crossing rather than kept: with the crossing row's registers beside it the kernel
+    // would need more than a third of a SIMD's registers, and three waves per chain could not all be resident)
+    const unsigned long long k0 = PENGK_CLOCK();
+    Row mine;
+    mine.read(lds + lane * SEG_STRIDE);
+    const unsigned long long k1 = PENGK_CLOCK();
+    PENGK_STAT_ADD(4, k1 - k0);
     PENGK_STAT_ADD(1, 1);
     const unsigned long long k2 = PENGK_CLOCK();
     if (bits(s) >= INF_BITS) return s;  // +inf + t = +inf
@@ -216,20 +218,28 @@ __device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, flo
   }
 }
 
-// The term source of a chain: load(b, lane, R) fetches block b into 64 registers, deposit(lane, R, lds) spreads them
-// over the LDS rows.
+// The term source of a chain, for NF fetching waves: load<NF>(b, part, lane, R) fetches share `part` of block b into
+// 64 / NF registers, deposit<NF>(part, lane, R, lds) spreads them over the LDS rows.
 //
-// Two waves per chain (a workgroup of 128 threads, every thread calls fold_chain): moving a block through a wave --
-// sixteen 16-byte loads, sixteen LDS writes, the wait for them -- takes as long as evaluating it, so wave 1 only
-// fetches (block i into buffer i & 1, the loads of block i + 1 in flight) while wave 0 only evaluates (block i - 1
-// from the other buffer), one workgroup barrier per block.  The result is returned in wave 0 (wave 1 returns 0).
-// CHECK: wave 1 looks at every term; a chain with a negative / non-finite term is summed by the plain loop `serial`.
-constexpr uint32_t CHAIN_THREADS = 128;
+// 1 + FETCH_WAVES waves per chain (a workgroup of CHAIN_THREADS threads, every thread calls fold_chain): moving a
+// block through a wave -- sixteen 16-byte loads, sixteen LDS writes, the wait for them -- takes as long as evaluating
+// it, so the waves behind wave 0 only fetch, 1 / FETCH_WAVES of a block each (block i into buffer i & 1, the loads of
+// block i + 1 in flight), while wave 0 only evaluates (block i - 1 from the other buffer); one workgroup barrier per
+// block.  The result is returned in wave 0 (the others return 0).
+// CHECK: the fetching waves look at every term; a chain with a negative / non-finite term is summed by the plain loop
+// `serial`.
+#ifndef PENGK_FETCH_WAVES
+#define PENGK_FETCH_WAVES 1  // measured (16 PWMs x 10 iterations, W = 10): 1 -> 1.02 ms, 2 -> 1.09, 4 -> 1.11
+#endif
+constexpr uint32_t FETCH_WAVES = PENGK_FETCH_WAVES;  // each fetches 1 / FETCH_WAVES of every block
+constexpr uint32_t CHAIN_THREADS = 64u * (1u + FETCH_WAVES);
 constexpr uint32_t CHAIN_LDS_FLOATS = 2u * LDS_FLOATS + 4u;  // two row buffers + the flag word
 template <class Source, bool CHECK>
 __device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks, float* lds, uint32_t thread) {
   const uint32_t lane = thread & 63u;
-  const bool fetcher = (uint32_t)__builtin_amdgcn_readfirstlane((int)(thread >> 6)) != 0u;  // wave-uniform
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(thread >> 6));  // wave-uniform
+  const bool fetcher = wave != 0u;
+  const uint32_t part = wave - 1u;  // which share of a block this fetch wave moves
   volatile uint32_t* bad = reinterpret_cast<volatile uint32_t*>(lds + 2u * LDS_FLOATS);
   if (CHECK) {
     if (thread == 0) *bad = 0u;
@@ -238,20 +248,20 @@ __device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks
   Stats st;
   float s = 0.0f;
   if (fetcher) {
-    float R[64];
-    src.load(0u, lane, R);
+    float R[64 / FETCH_WAVES];
+    src.template load<FETCH_WAVES>(0u, part, lane, R);
 #pragma unroll 1
     for (uint32_t i = 0; i <= n_blocks; ++i) {
       if (i < n_blocks) {
         if (CHECK) {
           uint32_t m = 0;
 #pragma unroll
-          for (int k = 0; k < 64; ++k) m = max(m, bits(R[k]));
+          for (int k = 0; k < (int)(64 / FETCH_WAVES); ++k) m = max(m, bits(R[k]));
           if (__builtin_amdgcn_ballot_w64(m > 0x7F7FFFFFu) && lane == 0) *bad = 1u;
         }
         const unsigned long long c0 = PENGK_CLOCK();
-        src.deposit(lane, R, lds + (i & 1u) * LDS_FLOATS);
-        if (i + 1u < n_blocks) src.load(i + 1u, lane, R);
+        src.template deposit<FETCH_WAVES>(part, lane, R, lds + (i & 1u) * LDS_FLOATS);
+        if (i + 1u < n_blocks) src.template load<FETCH_WAVES>(i + 1u, part, lane, R);
         PENGK_STAT_ADD(2, PENGK_CLOCK() - c0);
       }
       __syncthreads();

@@ -11,18 +11,21 @@ namespace {
 struct PlainTerms {
   const float* __restrict__ t;
   uint64_t n;
-  // term 64 k + lane of block b in R[k]; zero behind the end of the chain (s + 0 = s for every s >= +0)
-  __device__ __forceinline__ void load(uint32_t b, uint32_t lane, float (&R)[64]) const {
-    const uint64_t c0 = (uint64_t)b * seqsum::BLOCK + lane;
+  // share `part` of NF: terms 64 k + lane of block b, k = part * 64 / NF .., in R[k - part * 64 / NF]; zero behind the
+  // end of the chain (s + 0 = s for every s >= +0)
+  template <uint32_t NF>
+  __device__ __forceinline__ void load(uint32_t b, uint32_t part, uint32_t lane, float (&R)[64 / NF]) const {
+    const uint64_t c0 = (uint64_t)b * seqsum::BLOCK + (uint64_t)part * (seqsum::BLOCK / NF) + lane;
 #pragma unroll
-    for (uint32_t k = 0; k < 64u; ++k) {
+    for (uint32_t k = 0; k < 64u / NF; ++k) {
       const uint64_t c = c0 + 64u * k;
       R[k] = c < n ? t[c] : 0.0f;
     }
   }
-  __device__ __forceinline__ void deposit(uint32_t lane, const float (&R)[64], float* lds) const {
+  template <uint32_t NF>
+  __device__ __forceinline__ void deposit(uint32_t part, uint32_t lane, const float (&R)[64 / NF], float* lds) const {
 #pragma unroll
-    for (uint32_t k = 0; k < 64u; ++k) lds[k * seqsum::SEG_STRIDE + lane] = R[k];
+    for (uint32_t k = 0; k < 64u / NF; ++k) lds[(part * (64u / NF) + k) * seqsum::SEG_STRIDE + lane] = R[k];
   }
   // the plain loop, for chains with a negative or non-finite term (every lane computes the same value)
   __device__ float serial() const {
