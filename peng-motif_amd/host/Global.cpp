@@ -46,8 +46,14 @@ void Global::init(int nargs, char* args[]) {
   pengk_host::start_context();  // the device runtime starts while the FASTA files are read
   // both strands are handled inside the count; sequences are always read single stranded
   inputSequenceSet = new SequenceSet(inputSequenceFilename, true);
-  backgroundSequenceSet =
-      backgroundSequenceFilename ? new SequenceSet(backgroundSequenceFilename, true) : inputSequenceSet;
+  // Without --background-sequences the reference reads the input file a second time (src/Global.cpp:66-75) and so
+  // prints that file's warnings twice; the set is shared here, its warnings are replayed.
+  if (backgroundSequenceFilename) {
+    backgroundSequenceSet = new SequenceSet(backgroundSequenceFilename, true);
+  } else {
+    backgroundSequenceSet = inputSequenceSet;
+    std::cerr << inputSequenceSet->diagnostics() << std::flush;
+  }
 }
 
 void Global::destruct() {

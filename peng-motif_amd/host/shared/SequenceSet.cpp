@@ -164,6 +164,7 @@ void SequenceSet::readFASTA() {
   for (size_t r = 0; r < R; ++r) {
     if (len[r] == 0) {
       std::cerr << "Warning: Ignore FASTA entry without sequence: " << path_ << std::endl;
+      diagnostics_ += "Warning: Ignore FASTA entry without sequence: " + path_ + "\n";
       continue;
     }
     kept.push_back(r);
@@ -242,8 +243,10 @@ void SequenceSet::readFASTA() {
     const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
     const std::string& header = headers_.back();
     for (p = nl + 1; p < end; ++p)
-      if (*p != '\n' && lut[(uint8_t)*p] == 0)
+      if (*p != '\n' && lut[(uint8_t)*p] == 0) {
         std::cerr << "Warning: The FASTA file contains an undefined base: " << *p << " at sequence " << header << std::endl;
+        diagnostics_ += std::string("Warning: The FASTA file contains an undefined base: ") + *p + " at sequence " + header + "\n";
+      }
   }
   unsigned long base_counts[4] = {0, 0, 0, 0};
   for (auto& c : counts)

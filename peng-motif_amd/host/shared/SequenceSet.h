@@ -24,6 +24,9 @@ class SequenceSet {
   ~SequenceSet();
 
   std::string getSequenceFilepath() { return path_; }
+  // the warnings this set's constructor wrote to stderr (a caller that re-uses the set where the reference reads the
+  // file again replays them)
+  const std::string& diagnostics() const { return diagnostics_; }
   std::vector<Sequence*> getSequences();  // materialises views on first use
   size_t getN() { return offs_.size() - 1; }
   unsigned int getMinL() { return minL_; }
@@ -37,6 +40,7 @@ class SequenceSet {
  private:
   void readFASTA();
   std::string path_;
+  std::string diagnostics_;
   bool single_stranded_;
   uint8_t* codes_ = nullptr;
   std::vector<int64_t> offs_;

@@ -143,6 +143,41 @@ def test_cli_random_inputs_against_reference_binary(tmp_path, seed, flags):
     compare_outputs(*outs["here"], outs["ref"][0], outs["ref"][1], outs["ref"][2], "--no-em" not in flags)
 
 
+@pytest.mark.parametrize("with_bg", [False, True])
+def test_cli_stderr_warnings_match_the_reference(tmp_path, with_bg):
+    """stderr: the reference warns about records without sequence as it meets them and about undefined bases only in the
+    LAST record of a file (src/shared/SequenceSet.cpp:395-405), once per SequenceSet -- i.e. twice for the input file when
+    no --background-sequences is given, because it reads that file a second time (src/Global.cpp:66-75).  Same lines, same
+    order here."""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/peng_motif_ref not present (the reference is only built in the build container)")
+    rng = np.random.default_rng(77)
+    recs = []
+    for i in range(400):
+        s = "".join(rng.choice(list("ACGT"), size=80))
+        if i % 3 == 0:
+            s = s[:30] + "GCTGAGTCAT" + s[40:]
+        if i == 17:
+            s = s[:10] + "N" + s[11:]          # an undefined base in the middle of the file: silent in the reference
+        recs.append(">r%d\n%s\n" % (i, s))
+    recs.insert(100, ">empty\n")               # a record without sequence
+    recs.append(">last\nACGTNACGTXACGT" + "ACGT" * 10 + "\n")  # undefined bases in the last record
+    fa = tmp_path / "warn.fa"
+    fa.write_text("".join(recs))
+    flags = ["-w", "8"]
+    if with_bg:
+        bg = tmp_path / "bg.fa"
+        bg.write_text("".join(">b%d\n%s\n" % (i, "".join(rng.choice(list("ACGT"), size=100))) for i in range(200)) + ">blast\nACGTRACGT" + "A" * 30 + "\n")
+        flags += ["--background-sequences", str(bg)]
+    warn = {}
+    for tag, exe in (("ref", REF_CLI), ("here", CLI)):
+        r = subprocess.run([exe, str(fa)] + flags + ["-o", str(tmp_path / (tag + ".meme"))], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr.decode()[-2000:])
+        warn[tag] = [l for l in r.stderr.decode().split("\n") if l.startswith("Warning:")]
+    assert len(warn["ref"]) >= 3
+    assert warn["here"] == warn["ref"]
+
+
 def test_host_selftest_reference_unit_checks():
     """the checks of the reference's gtest fixture (test/test_base_pattern.cpp) on this repository's classes,
     on the reference fixture's own 3-record input"""
