@@ -38,8 +38,9 @@ int main(int nargs, char** args) {
   if (pengk_host::rank() != 0 && !std::freopen("/dev/null", "w", stdout)) return 1;
   Global::init(nargs, args);
   clock.lap("read FASTA");
-  pengk_host::context();  // fail early (exit 1) when no gfx950 device is present: there is no CPU path
-  clock.lap("device context");
+  // (the device context is being created on a helper thread since Global::init; nothing waits for it before the packed
+  // sequences are ready for upload -- BasePattern's first device call -- and a machine without a gfx950 device fails
+  // there, loudly: there is no CPU path)
 
   const int bg_model_order = std::max(Global::bgModelOrder, Global::maxOptBgModelOrder);
   BackgroundModel* bgModel =

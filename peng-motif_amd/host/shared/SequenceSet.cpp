@@ -12,6 +12,20 @@
 #include <limits>
 #include <thread>
 
+void* sequence_set_huge_alloc(std::size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  const std::size_t huge = (std::size_t)2 << 20;
+  if (bytes < 2 * huge) return std::malloc(bytes);
+  const std::size_t rounded = (bytes + huge - 1) / huge * huge;
+  void* p = nullptr;
+  if (posix_memalign(&p, huge, rounded) != 0) p = nullptr;
+  // advisory: without THP these are ordinary pages.  PENGK_NO_HUGEPAGES=1 skips it (on a host whose memory is so
+  // fragmented that the kernel has to compact before it can hand out 2 MiB pages, the first touch stalls instead)
+  static const bool want = std::getenv("PENGK_NO_HUGEPAGES") == nullptr;
+  if (p && want) madvise(p, rounded, MADV_HUGEPAGE);
+  return p;
+}
+
 SequenceSet::SequenceSet(std::string sequenceFilepath, bool single_stranded, std::string intensityFilepath) {
   if (Alphabet::getSize() == 0) {
     std::cerr << "Error: Initialize Alphabet before constructing a SequenceSet" << std::endl;
@@ -42,9 +56,9 @@ std::vector<Sequence*> SequenceSet::getSequences() {
     for (size_t i = 0; i < n; ++i) {
       const int L = (int)(offs_[i + 1] - offs_[i]);
       if (single_stranded_) {
-        sequences_.push_back(Sequence::view(codes_ + offs_[i], L, headers_[i]));
+        sequences_.push_back(Sequence::view(codes_ + offs_[i], L, header(i)));
       } else {
-        sequences_.push_back(new Sequence(codes_ + offs_[i], L, headers_[i], std::vector<int>(), false));
+        sequences_.push_back(new Sequence(codes_ + offs_[i], L, header(i), std::vector<int>(), false));
       }
     }
     materialised_ = true;
@@ -88,17 +102,37 @@ void SequenceSet::readFASTA() {
     exit(1);
   }
   size_t size = (size_t)sb.st_size;
-  const char* text = nullptr;
+  // The file is copied into an anonymous buffer on huge pages by all threads (pread) instead of mapped: mapping touches
+  // every 4 KiB page of the page cache once per process, and that first touch was most of the reader's time for a
+  // 2 GB input (the three passes below then also run on 2 MiB pages).
+  char* text = nullptr;
   if (size) {
-    text = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (text == MAP_FAILED) {
-      std::cerr << "Error: Cannot open FASTA file: " << path_ << std::endl;
+    text = (char*)sequence_set_huge_alloc(size);
+    if (!text) {
+      std::cerr << "Error: out of memory reading " << path_ << std::endl;
       exit(1);
     }
-    madvise((void*)text, size, MADV_SEQUENTIAL);
+    const unsigned nr = host_threads(size);
+    std::vector<int> failed(nr, 0);
+    parallel_for(nr, [&](unsigned t) {
+      size_t at = size * t / nr;
+      const size_t hi = size * (t + 1) / nr;
+      while (at < hi) {
+        const ssize_t got = pread(fd, text + at, hi - at, (off_t)at);
+        if (got <= 0) {
+          failed[t] = 1;
+          return;
+        }
+        at += (size_t)got;
+      }
+    });
+    for (int f : failed)
+      if (f) {
+        std::cerr << "Error: Cannot open FASTA file: " << path_ << std::endl;
+        exit(1);
+      }
   }
   close(fd);
-  const size_t mapped = size;
   // the reference's getline(...).good() loop never yields a final line without '\n'
   while (size && text[size - 1] != '\n') --size;
 
@@ -132,14 +166,16 @@ void SequenceSet::readFASTA() {
   hdr.push_back(size);
 
   // ---- 2. measure every record (sequence length, spaces) ---------------------------------------------------
-  std::vector<uint32_t> len(R, 0);
+  raw_vector<uint32_t> len(R), hlen(R);  // both written for every record below
   std::vector<int> bad(nt, 0);
   auto record_cut = [&](unsigned t) { return (size_t)((uint64_t)R * t / nt); };
   parallel_for(nt, [&](unsigned t) {
     for (size_t r = record_cut(t); r < record_cut(t + 1); ++r) {
       const char* p = text + hdr[r];
       const char* end = text + hdr[r + 1];
-      p = (const char*)memchr(p, '\n', (size_t)(end - p)) + 1;  // skip the header line (terminated: size ends on '\n')
+      const char* h_end = (const char*)memchr(p, '\n', (size_t)(end - p));  // the header line (terminated: size ends on '\n')
+      hlen[r] = (uint32_t)(h_end - p - 1);
+      p = h_end + 1;
       size_t n = 0;
       while (p < end) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
@@ -158,23 +194,74 @@ void SequenceSet::readFASTA() {
     }
 
   // ---- 3. offsets of the kept records, headers -------------------------------------------------------------
-  std::vector<size_t> kept;
-  kept.reserve(R);
-  int64_t total = 0;
-  for (size_t r = 0; r < R; ++r) {
-    if (len[r] == 0) {
-      std::cerr << "Warning: Ignore FASTA entry without sequence: " << path_ << std::endl;
-      diagnostics_ += "Warning: Ignore FASTA entry without sequence: " + path_ + "\n";
-      continue;
+  // Two parallel passes over the records (totals per thread range, then every range writes its own entries): with
+  // push_backs, one std::string per header and value-initialised arrays this step ran on one thread and was the
+  // longest of the reader at 10M records.
+  struct Part {
+    size_t kept = 0, empty = 0;
+    int64_t bases = 0;
+    uint64_t hbytes = 0;
+    uint32_t maxL = 0, minL = std::numeric_limits<uint32_t>::max();
+  };
+  std::vector<Part> part(nt);
+  parallel_for(nt, [&](unsigned t) {
+    Part p;
+    for (size_t r = record_cut(t); r < record_cut(t + 1); ++r) {
+      const uint32_t l = len[r];
+      if (l == 0) {
+        ++p.empty;
+        continue;
+      }
+      ++p.kept;
+      p.bases += l;
+      p.hbytes += hlen[r];
+      p.maxL = l > p.maxL ? l : p.maxL;
+      p.minL = l < p.minL ? l : p.minL;
     }
-    kept.push_back(r);
-    total += len[r];
-    offs_.push_back(total);
-    if (len[r] > maxL_) maxL_ = len[r];
-    if (len[r] < minL_) minL_ = len[r];
+    part[t] = p;
+  });
+  size_t K = 0, n_empty = 0;
+  int64_t total = 0;
+  uint64_t htotal = 0;
+  std::vector<Part> base(nt);  // what lies in front of each thread's range
+  for (unsigned t = 0; t < nt; ++t) {
+    base[t].kept = K;
+    base[t].bases = total;
+    base[t].hbytes = htotal;
+    K += part[t].kept;
+    n_empty += part[t].empty;
+    total += part[t].bases;
+    htotal += part[t].hbytes;
+    if (part[t].kept) {
+      if (part[t].maxL > maxL_) maxL_ = part[t].maxL;
+      if (part[t].minL < minL_) minL_ = part[t].minL;
+    }
   }
-  headers_.resize(kept.size());
-  codes_ = (uint8_t*)std::malloc(total ? (size_t)total : 1);
+  for (size_t i = 0; i < n_empty; ++i) {  // (identical lines: the reference prints one per empty record as it meets it)
+    std::cerr << "Warning: Ignore FASTA entry without sequence: " << path_ << std::endl;
+    diagnostics_ += "Warning: Ignore FASTA entry without sequence: " + path_ + "\n";
+  }
+  raw_vector<size_t> kept(K);
+  offs_.resize(K + 1);
+  hdr_off_.resize(K + 1);
+  offs_[0] = 0;
+  hdr_off_[0] = 0;
+  parallel_for(nt, [&](unsigned t) {
+    size_t k = base[t].kept;
+    int64_t at = base[t].bases;
+    uint64_t hat = base[t].hbytes;
+    for (size_t r = record_cut(t); r < record_cut(t + 1); ++r) {
+      if (len[r] == 0) continue;
+      kept[k] = r;
+      at += len[r];
+      hat += hlen[r];
+      ++k;
+      offs_[k] = at;
+      hdr_off_[k] = hat;
+    }
+  });
+  hdr_pool_.resize((size_t)htotal);
+  codes_ = (uint8_t*)sequence_set_huge_alloc((size_t)total);
   if (!codes_) {
     std::cerr << "Error: out of memory reading " << path_ << std::endl;
     exit(1);
@@ -191,7 +278,6 @@ void SequenceSet::readFASTA() {
     standard &= lut[c] == (u == 'A') + 2 * (u == 'C') + 3 * (u == 'G') + 4 * (u == 'T');
   }
   std::vector<std::vector<unsigned long>> counts(nt, std::vector<unsigned long>(5, 0));
-  const size_t K = kept.size();
   parallel_for(nt, [&](unsigned t) {
     unsigned long* bc = counts[t].data();
     for (size_t k = (size_t)((uint64_t)K * t / nt); k < (size_t)((uint64_t)K * (t + 1) / nt); ++k) {
@@ -199,8 +285,8 @@ void SequenceSet::readFASTA() {
       const char* p = text + hdr[r];
       const char* end = text + hdr[r + 1];
       const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-      // ">" alone: the header is the 1-based index among the kept records (reference: N+1)
-      headers_[k] = (nl - p == 1) ? std::to_string(k + 1) : std::string(p + 1, (size_t)(nl - p - 1));
+      // (">" alone: an empty header, read back as the 1-based index among the kept records -- reference: N+1)
+      if (nl - p > 1) memcpy(hdr_pool_.data() + hdr_off_[k], p + 1, (size_t)(nl - p - 1));
       p = nl + 1;
       uint8_t* out = codes_ + offs_[k];
       while (p < end) {
@@ -241,7 +327,7 @@ void SequenceSet::readFASTA() {
     const char* p = text + hdr[R - 1];
     const char* end = text + hdr[R];
     const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-    const std::string& header = headers_.back();
+    const std::string header = this->header(K - 1);
     for (p = nl + 1; p < end; ++p)
       if (*p != '\n' && lut[(uint8_t)*p] == 0) {
         std::cerr << "Warning: The FASTA file contains an undefined base: " << *p << " at sequence " << header << std::endl;
@@ -253,5 +339,5 @@ void SequenceSet::readFASTA() {
     for (int i = 0; i < 4; ++i) base_counts[i] += c[i + 1];
   const unsigned long sum = base_counts[0] + base_counts[1] + base_counts[2] + base_counts[3];
   for (int i = 0; i < 4; ++i) base_freq_[i] = (float)base_counts[i] / (float)sum;
-  if (text) munmap((void*)text, mapped);
+  std::free(text);
 }
