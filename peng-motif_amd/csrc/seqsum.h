@@ -24,6 +24,7 @@
 // A term with its sign bit set, an infinity or a NaN breaks the monotonicity; callers route such chains to a plain
 // serial loop (em.hip keeps its serial fold kernel for that; fold_chain<.., true> checks and falls back itself).
 // One wave evaluates; a second wave of the workgroup keeps it fed (fold_chain).
+// tests/test_seqsum_model.py restates the arithmetic in numpy float32 (CPU); tests/test_gpu_seqsum.py checks this code.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
