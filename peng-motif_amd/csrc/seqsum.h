@@ -175,8 +175,10 @@ __device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, flo
       d += row_shr<2>(0.0f, d);
       d += row_shr<4>(0.0f, d);
       d += row_shr<8>(0.0f, d);
-      const float r1 = lane_value(d, 15), r2 = r1 + lane_value(d, 31), r3 = r2 + lane_value(d, 47);
-      d += rw == 1u ? r1 : rw == 2u ? r2 : rw == 3u ? r3 : 0.0f;
+      // across the rows of 16: lane 15 of a row into every lane of the next row (rows 1 and 3), then lane 31 -- by now
+      // the total of rows 0 and 1 -- into rows 2 and 3: the wave64 scan idiom of gfx9's DPP broadcasts
+      d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+      d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
       end = s + d;
     } else {
       // inclusive prefix inside each row of 16 lanes: (rows l-d .. of the earlier lanes) then (this lane's)
