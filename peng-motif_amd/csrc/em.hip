@@ -321,20 +321,41 @@ __global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict
   __syncthreads();
   const uint32_t np = 1u << (2 * W);
   float* out = wbuf + (size_t)pw * ((size_t)np << (T0 ? 1 : 0));
-  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
-    float pr = 1.0f;  // src/peng.cpp:180-197: ((1*pwm[0][x0])*pwm[1][x1])...
+  // A thread takes the 16 x that share their low W-2 digits: the product over those positions is built once, in the
+  // reference's order ((1*pwm[0][x0])*pwm[1][x1])... (src/peng.cpp:180-197), and the last two factors are applied per x
+  // -- the same multiplications in the same order for every x, 1.25 per x instead of W (the ten LDS look-ups and
+  // multiplications were 40 % of this kernel; the rest is its three IEEE divisions).
+  constexpr uint32_t NLOW = 1u << (2 * W - 4);
+  float hi0[4], hi1[4];
 #pragma unroll
-    for (int p = 0; p < W; ++p) pr = pr * s_pwm[p * 4 + ((x >> (2 * p)) & 3u)];
-    const float odds = pr / bg[x];
-    const float v = ((float)counts[x] * saturation) / (1 + saturation / odds);  // :124-125
-    out[x] = v;
-    // position 0's cells take every fourth x: a second, permuted copy of the table with the four cells' terms contiguous
-    // (term c of cell a at np + a 4^(W-1) + c) lets the scan fetch them like the cells of position W-1 (otherwise each of
-    // the four cells moves every line and issues four times the loads -- they were the last to finish)
-    if (T0) out[np + (x & 3u) * (np / 4u) + (x >> 2)] = v;
-    // a negative or non-finite weight (degenerate PWM / background entries): this PWM's cells are summed by the plain
-    // serial fold instead of the scan (seqsum.h)
-    if (__float_as_uint(v) > 0x7F7FFFFFu) bad[pw] = 1u;
+  for (int a = 0; a < 4; ++a) {
+    hi0[a] = s_pwm[(W - 2) * 4 + a];
+    hi1[a] = s_pwm[(W - 1) * 4 + a];
+  }
+  for (uint32_t low = blockIdx.x * blockDim.x + threadIdx.x; low < NLOW; low += gridDim.x * blockDim.x) {
+    float pl = 1.0f;
+#pragma unroll
+    for (int p = 0; p < W - 2; ++p) pl = pl * s_pwm[p * 4 + ((low >> (2 * p)) & 3u)];
+#pragma unroll
+    for (uint32_t a8 = 0; a8 < 4u; ++a8) {
+      const float p8 = pl * hi0[a8];
+#pragma unroll
+      for (uint32_t a9 = 0; a9 < 4u; ++a9) {
+        const uint32_t x = low | (a8 << (2 * W - 4)) | (a9 << (2 * W - 2));
+        const float pr = p8 * hi1[a9];
+        const float odds = pr / bg[x];
+        const float v = ((float)counts[x] * saturation) / (1 + saturation / odds);  // :124-125
+        out[x] = v;
+        // position 0's cells take every fourth x: a second, permuted copy of the table with the four cells' terms
+        // contiguous (term c of cell a at np + a 4^(W-1) + c) lets the scan fetch them like the cells of position W-1
+        // (otherwise each of the four cells moves every line and issues four times the loads -- they were the last to
+        // finish)
+        if (T0) out[np + (x & 3u) * (np / 4u) + (x >> 2)] = v;
+        // a negative or non-finite weight (degenerate PWM / background entries): this PWM's cells are summed by the
+        // plain loop of the finalize kernel instead of the scan (seqsum.h)
+        if (__float_as_uint(v) > 0x7F7FFFFFu) bad[pw] = 1u;
+      }
+    }
   }
 }
 
@@ -699,7 +720,7 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)batch * sizeof(uint32_t), ctx->stream));
   // cells of at least four blocks are summed by the scan (seqsum.h; flagged PWMs by the finalize kernel's plain loop),
   // the short chains of W <= 6 by the dependent-addition fold
-  const unsigned wb = (unsigned)std::min<size_t>((np + 255) / 256, 1024);
+  const unsigned wb = (unsigned)std::min<size_t>((np / 16 + 255) / 256, 1024);  // a thread per 16 x
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
     for (int it = 0; it < max_it; ++it) {
