@@ -907,9 +907,16 @@ __global__ void bg_finish_fused_kernel(const uint32_t* __restrict__ partials, ui
   {  // 12 strands of 84 threads each sum every 12th block; fixed order -> deterministic
     const int bin = t % 84, strand = t / 84;
     if (strand < 12) {
-      unsigned long long s = 0;
-      for (uint32_t b = strand; b < n_blocks; b += 12) s += partials[(size_t)b * 84 + bin];
-      part[strand][bin] = s;
+      // eight loads in flight per thread (integer sums: any order gives the same value; one dependent load after the
+      // other made this one-workgroup kernel 25 us long)
+      unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t b = strand;
+      for (; b + 7u * 12u < n_blocks; b += 8u * 12u) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) acc[j] += partials[(size_t)(b + 12u * j) * 84 + bin];
+      }
+      for (; b < n_blocks; b += 12) acc[0] += partials[(size_t)b * 84 + bin];
+      part[strand][bin] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
   }
   __syncthreads();
@@ -943,29 +950,40 @@ __global__ void bg_finish_fused_kernel(const uint32_t* __restrict__ partials, ui
 // BackgroundModel::calculateV (src/shared/BackgroundModel.cpp:490-530), one thread, float32 in the
 // reference's order.  Counts are converted integer -> float with round-to-nearest (the reference's
 // `int` counters overflow beyond 2^31 bases; below that the results are bit-identical).
-__global__ void bg_model_kernel(const unsigned long long* __restrict__ n, int K, float a0, float a1, float a2,
-                                float* __restrict__ V) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(128) void bg_model_kernel(const unsigned long long* __restrict__ n, int K, float a0, float a1, float a2,
+                                                       float* __restrict__ V) {
+  // one workgroup; every entry and every group of four is computed by its own thread with the reference's operations
+  // in the reference's order (a single thread walking all 84 entries took 21 us of dependent loads and divisions)
+  __shared__ float cnt[84];
+  __shared__ float v[84];
+  const int t = threadIdx.x;
   const float alpha[3] = {a0, a1, a2};
   const int off[3] = {0, 4, 20};
-  unsigned long long base_counts = 0;
-  for (int y = 0; y < 4; ++y) base_counts += n[y];
-  for (int y = 0; y < 4; ++y) V[y] = ((float)n[y] + alpha[0] * 0.25f) / ((float)base_counts + alpha[0]);
+  if (t < 84) cnt[t] = (float)n[t];
+  __shared__ float base_f;
+  if (t == 0) {
+    unsigned long long base_counts = 0;
+    for (int y = 0; y < 4; ++y) base_counts += n[y];
+    base_f = (float)base_counts;
+  }
+  __syncthreads();
+  if (t < 4) v[t] = (cnt[t] + alpha[0] * 0.25f) / (base_f + alpha[0]);
+  __syncthreads();
   for (int k = 1; k <= K; ++k) {
     const int ny = 1 << (2 * (k + 1));
     const int yk = 1 << (2 * k);
-    const unsigned long long* nk = n + off[k];
-    const unsigned long long* nk1 = n + off[k - 1];
-    float* vk = V + off[k];
-    const float* vk1 = V + off[k - 1];
-    for (int y = 0; y < ny; ++y) vk[y] = ((float)nk[y] + alpha[k] * vk1[y % yk]) / ((float)nk1[y / 4] + alpha[k]);
-    for (int g = 0; g < ny; g += 4) {
+    if (t < ny) v[off[k] + t] = (cnt[off[k] + t] + alpha[k] * v[off[k - 1] + t % yk]) / (cnt[off[k - 1] + t / 4] + alpha[k]);
+    __syncthreads();
+    if (t < ny / 4) {
+      float* g = v + off[k] + 4 * t;
       float factor = 0.0f;
-      for (int a = 0; a < 4; ++a) factor += vk[g + a];
-      for (int a = 0; a < 4; ++a) vk[g + a] /= factor;
+      for (int a = 0; a < 4; ++a) factor += g[a];
+      for (int a = 0; a < 4; ++a) g[a] /= factor;
     }
+    __syncthreads();
   }
-  for (int i = off[K] + (1 << (2 * (K + 1))); i < 84; ++i) V[i] = 0.0f;
+  const int used = off[K] + (1 << (2 * (K + 1)));
+  if (t < 84) V[t] = t < used ? v[t] : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1287,7 +1305,7 @@ int launch_bg_count(pengk_ctx* ctx, uint64_t* d_bg) {
 }
 
 int launch_bg_model(pengk_ctx* ctx, const uint64_t* d_bg, int K, const float* h_alpha, float* d_V) {
-  hipLaunchKernelGGL(bg_model_kernel, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long*)d_bg, K, h_alpha[0],
+  hipLaunchKernelGGL(bg_model_kernel, dim3(1), dim3(128), 0, ctx->stream, (const unsigned long long*)d_bg, K, h_alpha[0],
                      h_alpha[1], h_alpha[2], d_V);
   PENGK_HIP(hipGetLastError());
   return PENGK_OK;
