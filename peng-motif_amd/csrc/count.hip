@@ -907,13 +907,17 @@ __global__ void bg_finish_fused_kernel(const uint32_t* __restrict__ partials, ui
   {  // 12 strands of 84 threads each sum every 12th block; fixed order -> deterministic
     const int bin = t % 84, strand = t / 84;
     if (strand < 12) {
-      // eight loads in flight per thread (integer sums: any order gives the same value; one dependent load after the
-      // other made this one-workgroup kernel 25 us long)
+      // 32 loads in flight per thread (integer sums: any order gives the same value).  The partials were written by
+      // workgroups all over the chip and come from HBM: ~2 us per round trip, and one dependent load after the other made
+      // this one-workgroup kernel 25 us long.
       unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       uint32_t b = strand;
-      for (; b + 7u * 12u < n_blocks; b += 8u * 12u) {
+      for (; b + 31u * 12u < n_blocks; b += 32u * 12u) {
+        uint32_t v[32];
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; ++j) acc[j] += partials[(size_t)(b + 12u * j) * 84 + bin];
+        for (uint32_t j = 0; j < 32u; ++j) v[j] = partials[(size_t)(b + 12u * j) * 84 + bin];
+#pragma unroll
+        for (uint32_t j = 0; j < 32u; ++j) acc[j & 7u] += v[j];
       }
       for (; b < n_blocks; b += 12) acc[0] += partials[(size_t)b * 84 + bin];
       part[strand][bin] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
