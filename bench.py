@@ -140,20 +140,44 @@ def main():
 
     import ctypes as C
     rccl_ranks = 0
+    exchange_fallback = None
     if multi and backend == "nccl":
         # the exchange step runs in the C++ library (RCCL on the context's stream); torch.distributed only carries the
         # 128-byte communicator id to the ranks, the barriers around the timed region and the max over ranks
+        # Safety net (this path has only ever run with one rank on the build's one-GPU box): if the library's communicator
+        # cannot be created on some rank, ALL ranks agree to run the exchange as torch.distributed's RCCL all_reduce of
+        # the same device buffers instead, and the JSON line says so.
         box = [None]
-        if rank == 0:
-            buf = C.create_string_buffer(128)
-            pk._check(lib.pengk_comm_unique_id(buf))
-            box[0] = buf.raw
+        comm_error = None
+        try:
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                pk._check(lib.pengk_comm_unique_id(buf))
+                box[0] = buf.raw
+        except Exception as e:  # noqa: BLE001 -- reported below, after the ranks have agreed
+            comm_error = "pengk_comm_unique_id: %s" % e
         dist.broadcast_object_list(box, src=0)
-        pk._check(lib.pengk_comm_init(ctx.h, box[0], rank, world))
-        r_, w_ = C.c_int(), C.c_int()
-        pk._check(lib.pengk_comm_info(ctx.h, C.byref(r_), C.byref(w_)))
-        rccl_ranks = w_.value
-        assert (r_.value, w_.value) == (rank, world)
+        if box[0] is not None:
+            try:
+                if os.environ.get("PENGK_BENCH_BREAK_COMM"):  # test hook: exercise the safety net
+                    raise RuntimeError("forced by PENGK_BENCH_BREAK_COMM")
+                pk._check(lib.pengk_comm_init(ctx.h, box[0], rank, world))
+                r_, w_ = C.c_int(), C.c_int()
+                pk._check(lib.pengk_comm_info(ctx.h, C.byref(r_), C.byref(w_)))
+                assert (r_.value, w_.value) == (rank, world)
+                rccl_ranks = w_.value
+            except Exception as e:  # noqa: BLE001
+                comm_error = "pengk_comm_init: %s" % e
+        elif comm_error is None:
+            comm_error = "rank 0 could not create the communicator id"
+        agreed = torch.tensor([0 if comm_error else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            if rccl_ranks:
+                lib.pengk_comm_destroy(ctx.h)
+            rccl_ranks = 0
+            exchange_fallback = comm_error or "another rank could not create the library's communicator"
+            sys.stderr.write("bench.py rank %d: exchange falls back to torch.distributed all_reduce (%s)\n" % (rank, exchange_fallback))
 
     with torch.cuda.stream(ctx_stream):
         # ---- resident input: this rank's shard of the global synthetic set -------------------------
@@ -375,7 +399,9 @@ def main():
                        "n_seq_per_gpu": nseq, "seq_len": L, "W": W, "strand": args.strand, "ltot_global": ltot,
                        "parallelism": "sequence shards x%d, one all-reduce of the 4^W counts" % world,
                        "exchange": ("RCCL, %d rank(s), pengk_allreduce_tables on the kernels' stream" % rccl_ranks) if rccl_ranks
-                       else ("none (one rank)" if not multi else "gloo rehearsal through the host (not a measured configuration)"),
+                       else ("none (one rank)" if not multi else
+                             ("RCCL via torch.distributed all_reduce (fallback: %s)" % exchange_fallback) if exchange_fallback else
+                             "gloo rehearsal through the host (not a measured configuration)"),
                        "em_mode": mode_name[args.em_fast]},
             "components": {
                 "count_gbp_per_s_per_gpu": round(nseq * L / (count_ms * 1e-3) / 1e9, 3) if count_ms else None,

@@ -103,6 +103,22 @@ def test_one_rank_through_the_rccl_code_path_of_the_bench():
     assert forced["checks"] == plain["checks"]
 
 
+def test_bench_exchange_safety_net_when_the_library_communicator_fails():
+    """If pengk_comm_init fails on some rank at N > 1 the ranks agree (an all_reduce of a flag) to run the exchange as
+    torch.distributed's RCCL all_reduce of the same device buffers, and the JSON line says so: forced here with the one
+    rank of the test box (PENGK_BENCH_BREAK_COMM=1), same tables as the plain run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    broken = _bench(["--gpus", "1", "--nseq", "200000"], env=dict(os.environ, PENGK_BENCH_FORCE_COMM="1", PENGK_BENCH_BREAK_COMM="1"),
+                    launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port)])
+    plain = _bench(["--nseq", "200000"])
+    assert broken["config"]["exchange"].startswith("RCCL via torch.distributed all_reduce (fallback")
+    assert broken["checks"] == plain["checks"]
+
+
 def test_bench_starts_its_own_launcher_for_gpus_n():
     """`python bench.py --gpus 2` without a launcher starts torch.distributed.run itself (as a child process, before
     anything touches the GPU) and relays the one JSON line (gloo rehearsal: two ranks on the box's one GPU)."""
