@@ -620,7 +620,10 @@ __global__ __launch_bounds__(64 * SCATTER_WPW) void count_scatter_kernel(const u
 // a group of 64 leaves as one 256-byte line into region1[wave][bucket1][cap1].  16.5 KiB of rings per wave: three
 // waves per workgroup, three workgroups per CU.  (Round 1's level 1 appended in two half-waves per window into
 // 64-entry rings, with range tests and a sink bucket: 6.1 ms for a 12.5M-sequence shard.)
-constexpr int SCATTER12_WPW = 3;
+#ifndef PENGK_SCATTER12_WPW
+#define PENGK_SCATTER12_WPW 3
+#endif
+constexpr int SCATTER12_WPW = PENGK_SCATTER12_WPW;
 typedef ScatterEmit<Split12L1, 5, SCATTER12_WPW, uint32_t> Scatter12Emit;
 
 template <bool BOTH, bool BG>
