@@ -119,7 +119,9 @@ typedef struct pengk_packed {
 
 /* codes: the reference's byte codes (0 = other, A,C,G,T = 1..4) of all sequences back to back;
  * offs: n_seq+1 offsets into codes.  item_windows: maximum windows per scan item
- * (>= PENGK_MIN_ITEM_WINDOWS, <= 65535; 0 = PENGK_DEFAULT_ITEM_WINDOWS). */
+ * (>= PENGK_MIN_ITEM_WINDOWS, <= 65535; 0 = PENGK_DEFAULT_ITEM_WINDOWS).
+ * out->words / out->items are owned by the library (zero-filled blocks on transparent huge pages where the kernel
+ * grants them): release them with pengk_packed_free, never with free(). */
 int pengk_pack(const uint8_t* h_codes, const int64_t* h_offs, int64_t n_seq, int W, int item_windows,
                pengk_packed* out);
 void pengk_packed_free(pengk_packed* p);
