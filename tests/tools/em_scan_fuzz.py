@@ -1,0 +1,52 @@
+"""Differential soak of the serial EM: the scan (csrc/seqsum.h, em_serial_scan = 1) against the dependent-addition fold
+(em_serial_scan = 0) on random count tables, backgrounds and PWMs (GPU box) -- PWMs, iteration counts and `change` must be
+equal bit for bit.  usage: python tests/tools/em_scan_fuzz.py FIRST_SEED SECONDS"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import peng_motif_amd as pk
+
+seed0, seconds = int(sys.argv[1]), float(sys.argv[2])
+ctx = pk.Context(0)
+ctx.set_option("em_fast", 2)
+t_end = time.time() + seconds
+seed, n_pwm_total = seed0, 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    W = int(rng.choice([8, 8, 10]))
+    NP = 4 ** W
+    kind = int(rng.integers(0, 4))
+    if kind == 0:      # sparse counts (a small input)
+        c = np.zeros(NP, np.uint32)
+        idx = rng.integers(0, NP, NP // int(rng.integers(4, 200)))
+        c[idx] = rng.integers(1, 50, idx.size)
+    elif kind == 1:    # dense, heavy-tailed
+        c = rng.lognormal(2.0, 2.0, NP).astype(np.uint32)
+    elif kind == 2:    # huge counts on a few k-mers
+        c = rng.integers(0, 4, NP).astype(np.uint32)
+        c[rng.integers(0, NP, 20)] = rng.integers(10 ** 5, 10 ** 8, 20)
+    else:
+        c = rng.integers(0, 2000, NP).astype(np.uint32)
+    bg = (rng.dirichlet(np.ones(64), size=NP // 64).reshape(-1) * rng.choice([1.0, 1e-3, 1e-6])).astype(np.float32)
+    n = int(rng.integers(1, 20))
+    conc = float(rng.choice([0.05, 0.3, 1.0, 5.0]))   # small concentration: PWM entries down to 1e-30
+    pw = rng.dirichlet(np.full(4, conc), size=(n, W)).astype(np.float32)
+    pw = np.maximum(pw, np.float32(1e-30))
+    sat, thr, it = float(rng.choice([1e4, 1e3, 1e5])), float(rng.choice([0.0, 0.08])), int(rng.integers(1, 6))
+    counts = pk.DeviceArray.from_host(ctx, c)
+    bgd = pk.DeviceArray.from_host(ctx, bg)
+    out = {}
+    for scan in (1, 0):
+        ctx.set_option("em_serial_scan", scan)
+        out[scan] = ctx.em(W, pw, counts, bgd, sat, thr, it)
+    ctx.set_option("em_serial_scan", 1)
+    same = out[1][0].tobytes() == out[0][0].tobytes() and out[1][1].tolist() == out[0][1].tolist() and out[1][2].tobytes() == out[0][2].tobytes()
+    if not same:
+        print("MISMATCH seed", seed, "W", W, "kind", kind)
+        sys.exit(1)
+    n_pwm_total += n
+    seed += 1
+print("EM scan fuzz: seeds %d..%d, %d PWMs, scan == dependent fold bit for bit" % (seed0, seed - 1, n_pwm_total))
