@@ -260,8 +260,28 @@ int pengk_motif_similarity(pengk_ctx* ctx, int n, const float* h_pwm, const floa
  *
  *      Rendezvous: either the caller distributes rank 0's id itself (pengk_comm_unique_id + pengk_comm_init, e.g. over
  *      an existing launcher's store), or pengk_comm_init_env reads RANK / WORLD_SIZE / MASTER_ADDR from the launcher
- *      environment (torchrun, mpirun wrappers) and hands the id out over TCP port PENGK_COMM_PORT (default
- *      MASTER_PORT + 17).  With WORLD_SIZE unset or 1 every call below is a no-op that succeeds. */
+ *      environment (torchrun, mpirun wrappers), opens the process's host channel (below) and hands the id out over it.
+ *      With WORLD_SIZE unset or 1 every call below is a no-op that succeeds.
+ *
+ *      Host channel: what the HOST side of a sharded run has to agree on before any table exists -- every rank reads
+ *      only its byte range of the FASTA file (replaces the whole-file pass of src/shared/SequenceSet.cpp:285-447 per
+ *      rank), so the number of records, the base counts, the 84 background counters
+ *      (src/shared/BackgroundModel.cpp:60-84 -- additive in the counters, not in V) and the reader's warnings are
+ *      combined over a star of TCP connections to rank 0 on PENGK_COMM_PORT (default MASTER_PORT + 17), bound to
+ *      MASTER_ADDR.  Every socket operation has a deadline of PENGK_COMM_TIMEOUT seconds (default 120) and fails with
+ *      PENGK_ERR_DEVICE when a rank is missing; peers are admitted only with their rank and a token derived from the
+ *      launcher environment (plus PENGK_COMM_TOKEN, if set).  A rank that fails on its own must exit non-zero: its
+ *      peers then fail at their next host-channel call, or are torn down by the launcher.
+ *
+ *      PENGK_COMM_TRANSPORT=tcp makes pengk_comm_init_env skip RCCL and exchange the tables through host memory over
+ *      the host channel: a rehearsal transport for boxes with fewer GPUs than ranks (RCCL cannot put two ranks on one
+ *      GPU), never selected automatically. */
+int pengk_comm_host_init_env(void);                 /* idempotent; collective over the ranks of the job */
+int pengk_comm_host_info(int* rank_out, int* world_out);
+int pengk_comm_host_allgather(const void* h_send, void* h_recv, size_t bytes_per_rank);
+int pengk_comm_host_allreduce_u64(uint64_t* h_buf, size_t n); /* in-place sum */
+int pengk_comm_host_shutdown(void);
+
 #define PENGK_COMM_ID_BYTES 128
 int pengk_comm_unique_id(void* id_out /* PENGK_COMM_ID_BYTES */);
 int pengk_comm_init(pengk_ctx* ctx, const void* id, int rank, int world);

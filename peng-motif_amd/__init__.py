@@ -29,6 +29,8 @@ EXPORTS = [
     "pengk_seed_candidates", "pengk_iupac_aggregate", "pengk_em", "pengk_em_device", "pengk_sequential_sum_f32", "pengk_motif_similarity",
     "pengk_comm_unique_id", "pengk_comm_init", "pengk_comm_init_env", "pengk_comm_info", "pengk_comm_destroy",
     "pengk_allreduce_tables", "pengk_comm_check_bin_bound", "pengk_allgather",
+    "pengk_comm_host_init_env", "pengk_comm_host_info", "pengk_comm_host_allgather", "pengk_comm_host_allreduce_u64",
+    "pengk_comm_host_shutdown",
 ]
 
 
@@ -106,6 +108,11 @@ def lib():
         L.pengk_allreduce_tables.argtypes = [vp, C.c_int, vp, vp, vp]
         L.pengk_comm_check_bin_bound.argtypes = [vp]
         L.pengk_allgather.argtypes = [vp, vp, vp, C.c_size_t]
+        L.pengk_comm_host_init_env.argtypes = []
+        L.pengk_comm_host_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.pengk_comm_host_allgather.argtypes = [vp, vp, C.c_size_t]
+        L.pengk_comm_host_allreduce_u64.argtypes = [vp, C.c_size_t]
+        L.pengk_comm_host_shutdown.argtypes = []
         _lib = L
     return _lib
 

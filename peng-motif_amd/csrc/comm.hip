@@ -1,4 +1,4 @@
-// comm.hip -- C1: the one exchange step of the multi-GPU path, RCCL over xGMI, driven from the C++ side.
+// comm.hip -- C1: the one exchange step of the multi-GPU path, driven from the C++ side.
 //
 // One process per GPU.  Sequences shard by whole records, every rank counts its shard (K1 / K1b), then ONE
 // all-reduce(sum) of {uint32 counts[4^W], uint64 ltot, uint64 bg[84]} on the context's stream -- the non-overlap
@@ -6,16 +6,35 @@
 // which the pattern-space sweeps are replicated and the EM splits the PWM list (an all-gather returns the results).
 // The reference is a single process: nothing there corresponds to this file.
 //
-// librccl is opened on first use (dlopen), so single-GPU users of libpengk neither link nor initialise it.
+// Two layers:
+//  * the HOST CHANNEL of the process (pengk_comm_host_*): a star of TCP connections to rank 0, set up from the
+//    launcher environment.  It carries what the host side of a sharded run has to agree on before any table exists --
+//    the number of records, base counts, background counters and warnings of the FASTA shards -- and hands out the
+//    RCCL id.  Every socket operation has a deadline (PENGK_COMM_TIMEOUT seconds, default 120): a rank whose peer died
+//    fails with PENGK_ERR_DEVICE instead of blocking.  Peers introduce themselves with their rank and a token derived
+//    from the launcher environment before they are counted; a stray connection is dropped and never receives anything.
+//  * the DEVICE TRANSPORT of a context: RCCL over xGMI (default; librccl is opened on first use, so single-GPU users
+//    neither link nor initialise it), or -- PENGK_COMM_TRANSPORT=tcp -- the tables staged through host memory and
+//    summed over the host channel.  RCCL cannot put two ranks on one GPU; the tcp transport exists so that the whole
+//    multi-rank control flow of the CLI can be rehearsed on one card (tests/test_gpu_multirank.py).  It is a test
+//    transport, not a fallback: nothing selects it automatically.
 #include <arpa/inet.h>
 #include <dlfcn.h>
+#include <errno.h>
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
+#include <sys/time.h>
+#include <time.h>
 #include <unistd.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "pengk_internal.h"
 
@@ -73,12 +92,43 @@ int load_rccl() {
     if (r_ != 0) return fail(PENGK_ERR_DEVICE, "%s: %s", #call, g_rccl.GetErrorString(r_));   \
   } while (0)
 
-// ---- rendezvous without a launcher library: rank 0 hands the 128-byte id to every other rank over TCP ------------
+int env_int(const char* name, int fallback) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : fallback;
+}
+
+// ---- host channel ------------------------------------------------------------------------------------------------
+double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+struct HostChannel {
+  bool up = false;
+  int rank = 0, world = 1;
+  int timeout_s = 120;
+  std::vector<int> fds;  // rank 0: fds[r] for r >= 1; other ranks: fds[0] = the connection to rank 0
+  std::mutex mu;
+};
+HostChannel g_chan;
+
+void set_io_deadline(int fd, int seconds) {
+  timeval tv;
+  tv.tv_sec = seconds;
+  tv.tv_usec = 0;
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+  setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+  int one = 1;
+  setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+}
+
 int send_all(int fd, const void* p, size_t n) {
   const char* c = (const char*)p;
   while (n) {
     const ssize_t k = send(fd, c, n, MSG_NOSIGNAL);
-    if (k <= 0) return -1;
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) return -1;  // error, peer gone, or the deadline (EAGAIN with SO_SNDTIMEO)
     c += k;
     n -= (size_t)k;
   }
@@ -88,6 +138,7 @@ int recv_all(int fd, void* p, size_t n) {
   char* c = (char*)p;
   while (n) {
     const ssize_t k = recv(fd, c, n, 0);
+    if (k < 0 && errno == EINTR) continue;
     if (k <= 0) return -1;
     c += k;
     n -= (size_t)k;
@@ -95,57 +146,214 @@ int recv_all(int fd, void* p, size_t n) {
   return 0;
 }
 
-int exchange_id(rccl_unique_id* id, int rank, int world, const char* addr, int port) {
-  if (rank == 0) {
-    const int ls = socket(AF_INET, SOCK_STREAM, 0);
-    if (ls < 0) return fail(PENGK_ERR_DEVICE, "rendezvous: socket() failed");
-    int one = 1;
-    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-    sockaddr_in sa{};
-    sa.sin_family = AF_INET;
-    sa.sin_addr.s_addr = htonl(INADDR_ANY);
-    sa.sin_port = htons((uint16_t)port);
-    if (bind(ls, (sockaddr*)&sa, sizeof sa) != 0 || listen(ls, world) != 0) {
-      close(ls);
-      return fail(PENGK_ERR_DEVICE, "rendezvous: cannot listen on port %d", port);
-    }
-    for (int i = 1; i < world; ++i) {
-      const int fd = accept(ls, nullptr, nullptr);
-      if (fd < 0 || send_all(fd, id, sizeof *id) != 0) {
-        if (fd >= 0) close(fd);
-        close(ls);
-        return fail(PENGK_ERR_DEVICE, "rendezvous: handing the communicator id to a rank failed");
-      }
-      close(fd);
-    }
-    close(ls);
+void chan_close() {
+  for (int fd : g_chan.fds)
+    if (fd >= 0) close(fd);
+  g_chan.fds.clear();
+  g_chan.up = false;
+  g_chan.rank = 0;
+  g_chan.world = 1;
+}
+
+struct Hello {
+  uint64_t magic, token;
+  uint32_t rank, world;
+};
+constexpr uint64_t HELLO_MAGIC = 0x70656e676b633031ull;  // "pengkc01"
+
+// every rank of one job derives the same token from the launcher environment; PENGK_COMM_TOKEN adds a job secret
+uint64_t job_token(const char* addr, int port, int world) {
+  std::string s = std::string("pengk|") + addr + "|" + std::to_string(port) + "|" + std::to_string(world) + "|";
+  for (const char* name : {"TORCHELASTIC_RUN_ID", "PENGK_COMM_TOKEN"}) {
+    const char* e = getenv(name);
+    s += e ? e : "";
+    s += "|";
+  }
+  uint64_t h = 1469598103934665603ull;
+  for (unsigned char c : s) h = (h ^ c) * 1099511628211ull;
+  return h;
+}
+
+int chan_fail(const char* fmt, const char* addr, int port) {
+  chan_close();
+  return fail(PENGK_ERR_DEVICE, fmt, addr, port);
+}
+
+int chan_open(int rank, int world, const char* addr, int port, int timeout_s) {
+  g_chan.rank = rank;
+  g_chan.world = world;
+  g_chan.timeout_s = timeout_s;
+  if (world == 1) {
+    g_chan.up = true;
     return PENGK_OK;
   }
+  const uint64_t token = job_token(addr, port, world);
+  const double deadline = now_s() + timeout_s;
   addrinfo hints{}, *res = nullptr;
   hints.ai_family = AF_INET;
   hints.ai_socktype = SOCK_STREAM;
   char ports[16];
   snprintf(ports, sizeof ports, "%d", port);
   if (getaddrinfo(addr, ports, &hints, &res) != 0 || !res) return fail(PENGK_ERR_DEVICE, "rendezvous: cannot resolve %s", addr);
-  int rc = PENGK_ERR_DEVICE;
-  for (int attempt = 0; attempt < 600; ++attempt) {  // rank 0 may still be starting: up to a minute
-    const int fd = socket(AF_INET, SOCK_STREAM, 0);
-    if (fd < 0) break;
-    if (connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
-      rc = recv_all(fd, id, sizeof *id) == 0 ? PENGK_OK : PENGK_ERR_DEVICE;
-      close(fd);
-      break;
+
+  if (rank == 0) {
+    const int ls = socket(AF_INET, SOCK_STREAM, 0);
+    if (ls < 0) {
+      freeaddrinfo(res);
+      return fail(PENGK_ERR_DEVICE, "rendezvous: socket() failed");
     }
+    int one = 1;
+    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    // MASTER_ADDR's own interface, not every interface of the host; a name that resolves to an address this host does
+    // not own (NAT, a launcher quirk) falls back to all interfaces -- the token still keeps strangers out
+    bool bound = bind(ls, res->ai_addr, res->ai_addrlen) == 0;
+    if (!bound && errno == EADDRNOTAVAIL) {
+      sockaddr_in sa{};
+      sa.sin_family = AF_INET;
+      sa.sin_addr.s_addr = htonl(INADDR_ANY);
+      sa.sin_port = htons((uint16_t)port);
+      bound = bind(ls, (sockaddr*)&sa, sizeof sa) == 0;
+    }
+    freeaddrinfo(res);
+    if (!bound || listen(ls, world + 8) != 0) {
+      close(ls);
+      return fail(PENGK_ERR_DEVICE, "rendezvous: cannot listen on %s:%d", addr, port);
+    }
+    g_chan.fds.assign((size_t)world, -1);
+    int have = 0;
+    while (have < world - 1) {
+      const double left = deadline - now_s();
+      pollfd pf{ls, POLLIN, 0};
+      if (left <= 0 || poll(&pf, 1, (int)(left * 1000) + 1) <= 0) {
+        close(ls);
+        chan_close();
+        return fail(PENGK_ERR_DEVICE, "rendezvous: only %d of %d ranks reached %s:%d within %d s", have + 1, world, addr, port,
+                    timeout_s);
+      }
+      const int fd = accept(ls, nullptr, nullptr);
+      if (fd < 0) continue;
+      set_io_deadline(fd, 5);  // a connection that does not introduce itself at once is not a rank
+      Hello h{};
+      if (recv_all(fd, &h, sizeof h) != 0 || h.magic != HELLO_MAGIC || h.token != token || h.world != (uint32_t)world ||
+          h.rank == 0 || h.rank >= (uint32_t)world || g_chan.fds[h.rank] >= 0) {
+        close(fd);
+        continue;
+      }
+      set_io_deadline(fd, timeout_s);
+      g_chan.fds[h.rank] = fd;
+      ++have;
+    }
+    close(ls);
+    for (int r = 1; r < world; ++r)  // everyone is here: release the peers
+      if (send_all(g_chan.fds[r], &HELLO_MAGIC, sizeof HELLO_MAGIC) != 0) return chan_fail("rendezvous: a rank left %s:%d", addr, port);
+    g_chan.up = true;
+    return PENGK_OK;
+  }
+
+  int fd = -1;
+  while (now_s() < deadline) {  // rank 0 may still be starting
+    fd = socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) break;
+    if (connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
     close(fd);
-    usleep(100000);
+    fd = -1;
+    usleep(50000);
   }
   freeaddrinfo(res);
-  return rc == PENGK_OK ? PENGK_OK : fail(PENGK_ERR_DEVICE, "rendezvous: no communicator id from %s:%d", addr, port);
+  if (fd < 0) return fail(PENGK_ERR_DEVICE, "rendezvous: rank 0 not reachable at %s:%d within %d s", addr, port, timeout_s);
+  g_chan.fds.assign(1, fd);
+  set_io_deadline(fd, timeout_s);
+  const Hello h{HELLO_MAGIC, token, (uint32_t)rank, (uint32_t)world};
+  uint64_t ack = 0;
+  if (send_all(fd, &h, sizeof h) != 0 || recv_all(fd, &ack, sizeof ack) != 0 || ack != HELLO_MAGIC)
+    return chan_fail("rendezvous: rank 0 at %s:%d did not admit this rank (other ranks missing, or a different job)", addr, port);
+  g_chan.up = true;
+  return PENGK_OK;
 }
 
-int env_int(const char* name, int fallback) {
-  const char* e = getenv(name);
-  return e && *e ? atoi(e) : fallback;
+int chan_env_open() {
+  if (g_chan.up) return PENGK_OK;
+  const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0);
+  if (world < 1 || rank < 0 || rank >= world) return fail(PENGK_ERR_ARG, "RANK=%d WORLD_SIZE=%d", rank, world);
+  const char* addr = getenv("MASTER_ADDR");
+  if (!addr || !*addr) addr = "127.0.0.1";
+  // its own port: MASTER_PORT itself belongs to the launcher's store when there is one
+  const int port = env_int("PENGK_COMM_PORT", env_int("MASTER_PORT", 29500) + 17);
+  const int timeout_s = env_int("PENGK_COMM_TIMEOUT", 120);
+  return chan_open(rank, world, addr, port, timeout_s < 1 ? 1 : timeout_s);
+}
+
+int chan_lost() {
+  chan_close();
+  return fail(PENGK_ERR_DEVICE, "host channel: a rank did not answer (it failed, or the %d s deadline passed)", g_chan.timeout_s);
+}
+
+// recv[r * bytes ...) = rank r's send[0 .. bytes)
+int chan_allgather(const void* send, void* recv, size_t bytes) {
+  if (!g_chan.up) return fail(PENGK_ERR_ARG, "host channel is not open");
+  const int w = g_chan.world;
+  if (w == 1) {
+    if (recv != send) memmove(recv, send, bytes);
+    return PENGK_OK;
+  }
+  if (g_chan.rank == 0) {
+    memmove(recv, send, bytes);
+    for (int r = 1; r < w; ++r)
+      if (recv_all(g_chan.fds[r], (char*)recv + (size_t)r * bytes, bytes) != 0) return chan_lost();
+    for (int r = 1; r < w; ++r)
+      if (send_all(g_chan.fds[r], recv, (size_t)w * bytes) != 0) return chan_lost();
+    return PENGK_OK;
+  }
+  if (send_all(g_chan.fds[0], send, bytes) != 0 || recv_all(g_chan.fds[0], recv, (size_t)w * bytes) != 0) return chan_lost();
+  return PENGK_OK;
+}
+
+// in-place sum over the ranks
+template <class T>
+int chan_allreduce_sum(T* buf, size_t n) {
+  if (!g_chan.up) return fail(PENGK_ERR_ARG, "host channel is not open");
+  const int w = g_chan.world;
+  if (w == 1 || n == 0) return PENGK_OK;
+  const size_t bytes = n * sizeof(T);
+  if (g_chan.rank == 0) {
+    std::vector<T> in(n);
+    for (int r = 1; r < w; ++r) {
+      if (recv_all(g_chan.fds[r], in.data(), bytes) != 0) return chan_lost();
+      for (size_t i = 0; i < n; ++i) buf[i] += in[i];
+    }
+    for (int r = 1; r < w; ++r)
+      if (send_all(g_chan.fds[r], buf, bytes) != 0) return chan_lost();
+    return PENGK_OK;
+  }
+  if (send_all(g_chan.fds[0], buf, bytes) != 0 || recv_all(g_chan.fds[0], buf, bytes) != 0) return chan_lost();
+  return PENGK_OK;
+}
+
+int chan_bcast(void* buf, size_t bytes) {
+  if (!g_chan.up) return fail(PENGK_ERR_ARG, "host channel is not open");
+  if (g_chan.world == 1) return PENGK_OK;
+  if (g_chan.rank == 0) {
+    for (int r = 1; r < g_chan.world; ++r)
+      if (send_all(g_chan.fds[r], buf, bytes) != 0) return chan_lost();
+    return PENGK_OK;
+  }
+  return recv_all(g_chan.fds[0], buf, bytes) == 0 ? PENGK_OK : chan_lost();
+}
+
+bool use_tcp(const pengk_ctx* ctx) { return ctx->comm_transport == PENGK_TRANSPORT_TCP; }
+bool single(const pengk_ctx* ctx) { return ctx->comm_transport == PENGK_TRANSPORT_NONE; }
+
+// tcp transport: a device array summed over the ranks through host memory
+template <class T>
+int staged_allreduce(pengk_ctx* ctx, T* d_buf, size_t n) {
+  std::vector<T> h(n);
+  PENGK_HIP(hipMemcpyAsync(h.data(), d_buf, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  int rc = chan_allreduce_sum(h.data(), n);
+  if (rc) return rc;
+  PENGK_HIP(hipMemcpyAsync(d_buf, h.data(), n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  return PENGK_OK;
 }
 
 }  // namespace
@@ -153,6 +361,7 @@ int env_int(const char* name, int fallback) {
 void comm_release(pengk_ctx* ctx) {
   if (ctx->comm && g_rccl.handle) (void)g_rccl.CommDestroy((rccl_comm)ctx->comm);
   ctx->comm = nullptr;
+  ctx->comm_transport = PENGK_TRANSPORT_NONE;
   ctx->comm_rank = 0;
   ctx->comm_world = 1;
 }
@@ -163,6 +372,38 @@ using namespace pengk;
 
 extern "C" {
 
+// ---- host channel -------------------------------------------------------------------------------------------------
+int pengk_comm_host_init_env(void) {
+  std::lock_guard<std::mutex> lock(g_chan.mu);
+  return chan_env_open();
+}
+
+int pengk_comm_host_info(int* rank_out, int* world_out) {
+  std::lock_guard<std::mutex> lock(g_chan.mu);
+  if (rank_out) *rank_out = g_chan.up ? g_chan.rank : 0;
+  if (world_out) *world_out = g_chan.up ? g_chan.world : 1;
+  return PENGK_OK;
+}
+
+int pengk_comm_host_allgather(const void* h_send, void* h_recv, size_t bytes_per_rank) {
+  if (bytes_per_rank && (!h_send || !h_recv)) return fail(PENGK_ERR_ARG, "pengk_comm_host_allgather: NULL argument");
+  std::lock_guard<std::mutex> lock(g_chan.mu);
+  return chan_allgather(h_send, h_recv, bytes_per_rank);
+}
+
+int pengk_comm_host_allreduce_u64(uint64_t* h_buf, size_t n) {
+  if (n && !h_buf) return fail(PENGK_ERR_ARG, "pengk_comm_host_allreduce_u64: NULL argument");
+  std::lock_guard<std::mutex> lock(g_chan.mu);
+  return chan_allreduce_sum(h_buf, n);
+}
+
+int pengk_comm_host_shutdown(void) {
+  std::lock_guard<std::mutex> lock(g_chan.mu);
+  chan_close();
+  return PENGK_OK;
+}
+
+// ---- device transport ---------------------------------------------------------------------------------------------
 int pengk_comm_unique_id(void* id_out) {
   if (!id_out) return fail(PENGK_ERR_ARG, "pengk_comm_unique_id: NULL argument");
   int rc = load_rccl();
@@ -176,7 +417,7 @@ int pengk_comm_unique_id(void* id_out) {
 int pengk_comm_init(pengk_ctx* ctx, const void* id_bytes, int rank, int world) {
   if (!ctx || !id_bytes) return fail(PENGK_ERR_ARG, "pengk_comm_init: NULL argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(PENGK_ERR_ARG, "pengk_comm_init: rank %d of %d", rank, world);
-  if (ctx->comm) return fail(PENGK_ERR_ARG, "pengk_comm_init: the context already has a communicator");
+  if (!single(ctx)) return fail(PENGK_ERR_ARG, "pengk_comm_init: the context already has a communicator");
   int rc = load_rccl();
   if (rc) return rc;
   rc = enter(ctx);
@@ -186,6 +427,7 @@ int pengk_comm_init(pengk_ctx* ctx, const void* id_bytes, int rank, int world) {
   rccl_comm comm = nullptr;
   PENGK_RCCL(g_rccl.CommInitRank(&comm, world, id, rank));
   ctx->comm = comm;
+  ctx->comm_transport = PENGK_TRANSPORT_RCCL;
   ctx->comm_rank = rank;
   ctx->comm_world = world;
   return PENGK_OK;
@@ -193,34 +435,47 @@ int pengk_comm_init(pengk_ctx* ctx, const void* id_bytes, int rank, int world) {
 
 int pengk_comm_init_env(pengk_ctx* ctx) {
   if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
-  const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0);
-  if (world < 1 || rank < 0 || rank >= world) return fail(PENGK_ERR_ARG, "RANK=%d WORLD_SIZE=%d", rank, world);
-  const char* addr = getenv("MASTER_ADDR");
-  if (!addr || !*addr) addr = "127.0.0.1";
-  // its own port: MASTER_PORT itself belongs to the launcher's store when there is one
-  const int port = env_int("PENGK_COMM_PORT", env_int("MASTER_PORT", 29500) + 17);
-  int rc = load_rccl();
+  if (!single(ctx)) return fail(PENGK_ERR_ARG, "pengk_comm_init_env: the context already has a communicator");
+  std::unique_lock<std::mutex> lock(g_chan.mu);
+  int rc = chan_env_open();
   if (rc) return rc;
-  rccl_unique_id id;
-  memset(&id, 0, sizeof id);
-  if (rank == 0) PENGK_RCCL(g_rccl.GetUniqueId(&id));
-  if (world > 1) {
-    rc = exchange_id(&id, rank, world, addr, port);
-    if (rc) return rc;
+  const int rank = g_chan.rank, world = g_chan.world;
+  const char* transport = getenv("PENGK_COMM_TRANSPORT");
+  if (transport && strcmp(transport, "tcp") == 0) {
+    ctx->comm_transport = PENGK_TRANSPORT_TCP;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return PENGK_OK;
   }
-  return pengk_comm_init(ctx, &id, rank, world);
+  if (transport && *transport && strcmp(transport, "rccl") != 0)
+    return fail(PENGK_ERR_ARG, "PENGK_COMM_TRANSPORT=%s (rccl or tcp)", transport);
+  // every rank learns whether rank 0 could produce an id before anybody enters ncclCommInitRank
+  struct {
+    int32_t rc;
+    rccl_unique_id id;
+  } msg;
+  memset(&msg, 0, sizeof msg);
+  if (rank == 0) {
+    msg.rc = load_rccl();
+    if (!msg.rc && g_rccl.GetUniqueId(&msg.id) != 0) msg.rc = fail(PENGK_ERR_DEVICE, "ncclGetUniqueId failed");
+  }
+  rc = chan_bcast(&msg, sizeof msg);
+  lock.unlock();
+  if (rc) return rc;
+  if (msg.rc) return rank == 0 ? msg.rc : fail(PENGK_ERR_DEVICE, "rank 0 could not create an RCCL id");
+  return pengk_comm_init(ctx, &msg.id, rank, world);
 }
 
 int pengk_comm_info(pengk_ctx* ctx, int* rank_out, int* world_out) {
   if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
-  if (rank_out) *rank_out = ctx->comm ? ctx->comm_rank : 0;
-  if (world_out) *world_out = ctx->comm ? ctx->comm_world : 1;
+  if (rank_out) *rank_out = single(ctx) ? 0 : ctx->comm_rank;
+  if (world_out) *world_out = single(ctx) ? 1 : ctx->comm_world;
   return PENGK_OK;
 }
 
 int pengk_comm_destroy(pengk_ctx* ctx) {
   if (!ctx) return PENGK_OK;
-  if (ctx->comm) {
+  if (!single(ctx)) {
     PENGK_HIP(hipSetDevice(ctx->device));
     PENGK_HIP(hipStreamSynchronize(ctx->stream));
   }
@@ -231,16 +486,25 @@ int pengk_comm_destroy(pengk_ctx* ctx) {
 int pengk_allreduce_tables(pengk_ctx* ctx, int W, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg) {
   if (!ctx || !d_counts || !d_ltot) return fail(PENGK_ERR_ARG, "pengk_allreduce_tables: NULL argument");
   if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
-  if (!ctx->comm) return PENGK_OK;  // no communicator: the tables are already global (a 1-rank communicator still runs RCCL)
+  if (single(ctx)) return PENGK_OK;  // no communicator: the tables are already global (a 1-rank communicator still runs RCCL)
   int rc = enter(ctx);
   if (rc) return rc;
   const size_t np = (size_t)1 << (2 * W);
+  if (use_tcp(ctx)) {
+    std::lock_guard<std::mutex> lock(g_chan.mu);
+    rc = staged_allreduce(ctx, d_counts, np);
+    if (!rc) rc = staged_allreduce(ctx, d_ltot, 1);
+    if (!rc && d_bg) rc = staged_allreduce(ctx, d_bg, 84);
+    return rc;
+  }
   rccl_comm comm = (rccl_comm)ctx->comm;
+  // a group that was opened is always closed, whatever happens in between
   PENGK_RCCL(g_rccl.GroupStart());
-  PENGK_RCCL(g_rccl.AllReduce(d_counts, d_counts, np, RCCL_UINT32, RCCL_SUM, comm, ctx->stream));
-  PENGK_RCCL(g_rccl.AllReduce(d_ltot, d_ltot, 1, RCCL_UINT64, RCCL_SUM, comm, ctx->stream));
-  if (d_bg) PENGK_RCCL(g_rccl.AllReduce(d_bg, d_bg, 84, RCCL_UINT64, RCCL_SUM, comm, ctx->stream));
-  PENGK_RCCL(g_rccl.GroupEnd());
+  int bad = g_rccl.AllReduce(d_counts, d_counts, np, RCCL_UINT32, RCCL_SUM, comm, ctx->stream);
+  if (!bad) bad = g_rccl.AllReduce(d_ltot, d_ltot, 1, RCCL_UINT64, RCCL_SUM, comm, ctx->stream);
+  if (!bad && d_bg) bad = g_rccl.AllReduce(d_bg, d_bg, 84, RCCL_UINT64, RCCL_SUM, comm, ctx->stream);
+  const int end = g_rccl.GroupEnd();
+  if (bad || end) return fail(PENGK_ERR_DEVICE, "grouped ncclAllReduce: %s", g_rccl.GetErrorString(bad ? bad : end));
   return PENGK_OK;
 }
 
@@ -248,7 +512,11 @@ int pengk_comm_check_bin_bound(pengk_ctx* ctx) {
   if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
   if (!ctx->d_words) return fail(PENGK_ERR_ARG, "pengk_comm_check_bin_bound: no sequences attached");
   uint64_t bound = ctx->max_bin_bound;
-  if (ctx->comm) {
+  if (use_tcp(ctx)) {
+    std::lock_guard<std::mutex> lock(g_chan.mu);
+    int rc = chan_allreduce_sum(&bound, 1);
+    if (rc) return rc;
+  } else if (!single(ctx)) {
     int rc = enter(ctx);
     if (rc) return rc;
     rc = ensure_scratch(ctx, &ctx->d_misc, &ctx->misc_bytes, sizeof(uint64_t));
@@ -268,8 +536,21 @@ int pengk_allgather(pengk_ctx* ctx, const void* d_send, void* d_recv, size_t byt
   if (!ctx || !d_send || !d_recv) return fail(PENGK_ERR_ARG, "pengk_allgather: NULL argument");
   int rc = enter(ctx);
   if (rc) return rc;
-  if (!ctx->comm) {
+  if (single(ctx)) {
     if (d_send != d_recv) PENGK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
+    return PENGK_OK;
+  }
+  if (use_tcp(ctx)) {
+    std::vector<char> mine(bytes_per_rank), all(bytes_per_rank * (size_t)ctx->comm_world);
+    PENGK_HIP(hipMemcpyAsync(mine.data(), d_send, bytes_per_rank, hipMemcpyDeviceToHost, ctx->stream));
+    PENGK_HIP(hipStreamSynchronize(ctx->stream));
+    {
+      std::lock_guard<std::mutex> lock(g_chan.mu);
+      rc = chan_allgather(mine.data(), all.data(), bytes_per_rank);
+    }
+    if (rc) return rc;
+    PENGK_HIP(hipMemcpyAsync(d_recv, all.data(), all.size(), hipMemcpyHostToDevice, ctx->stream));
+    PENGK_HIP(hipStreamSynchronize(ctx->stream));
     return PENGK_OK;
   }
   PENGK_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, RCCL_UINT8, (rccl_comm)ctx->comm, ctx->stream));

@@ -45,9 +45,12 @@ struct pengk_ctx {
   int scatter_blocks_per_cu = 0; // tuning hook: workgroups per CU of the partitioned scan (0 = default)
   void* d_sim = nullptr;         // motif similarity grid: PWMs | complements | lengths | sites | scores
   size_t sim_bytes = 0;
-  void* comm = nullptr;          // RCCL communicator (comm.hip); NULL = single rank
+  void* comm = nullptr;          // RCCL communicator (comm.hip)
+  int comm_transport = 0;        // PENGK_TRANSPORT_*: how the tables of a multi-rank run are exchanged
   int comm_rank = 0, comm_world = 1;
 };
+
+enum { PENGK_TRANSPORT_NONE = 0, PENGK_TRANSPORT_RCCL = 1, PENGK_TRANSPORT_TCP = 2 };
 
 namespace pengk {
 

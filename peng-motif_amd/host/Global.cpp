@@ -44,6 +44,7 @@ void Global::init(int nargs, char* args[]) {
   readArguments(nargs, args);
   Alphabet::init(alphabetType);
   pengk_host::start_context();  // the device runtime starts while the FASTA files are read
+  pengk_host::start_sharded_ingest();  // multi-GPU run: every rank reads its own byte range of the files
   // both strands are handled inside the count; sequences are always read single stranded
   inputSequenceSet = new SequenceSet(inputSequenceFilename, true);
   // Without --background-sequences the reference reads the input file a second time (src/Global.cpp:66-75) and so
@@ -170,7 +171,7 @@ void Global::readArguments(int nargs, char* args[]) {
       printHelp();
       exit(0);
     } else {
-      std::cerr << "WARNING: Ignoring unknown option " << a << std::endl;
+      if (pengk_host::rank() == 0) std::cerr << "WARNING: Ignoring unknown option " << a << std::endl;
     }
   }
 }

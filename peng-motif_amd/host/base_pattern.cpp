@@ -32,12 +32,10 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
 
   // ---- sequences -> 2-bit stream + scan items (host packer resolves the N / skip scan rule) ----------
   pengk_host::Lap lap("    ");
-  // multi-GPU run: this rank scans its contiguous shard of whole records; the tables are summed below
-  size_t s_lo = 0, s_hi = sequence_set->getN();
-  const int n_ranks = pengk_host::world();
-  if (n_ranks > 1) pengk_host::shard_range(sequence_set->getN(), pengk_host::rank(), n_ranks, &s_lo, &s_hi);
+  // multi-GPU run: the sequence set of this rank holds its shard of whole records only (sharded ingest,
+  // shared/SequenceSet.h); the tables are summed below
   pengk_packed pk;
-  check(pengk_pack(sequence_set->codes(), sequence_set->offsets() + s_lo, (int64_t)(s_hi - s_lo), W, 0, &pk), "pengk_pack");
+  check(pengk_pack(sequence_set->codes(), sequence_set->offsets(), (int64_t)sequence_set->getLocalN(), W, 0, &pk), "pengk_pack");
   lap("pack");
   pengk_host::DeviceBuffer<uint64_t> d_words(pk.n_words), d_items(pk.n_items + 1), d_ltot(1);
   d_words.upload(pk.words, pk.n_words);

@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "Global.h"
+#include "shared/SequenceSet.h"
 
 namespace pengk_host {
 
@@ -33,10 +34,26 @@ int rank() {
 }
 static int device_index() { return launched() && std::getenv("LOCAL_RANK") ? env_int("LOCAL_RANK", 0) : Global::device; }
 
-void shard_range(size_t n, int r, int w, size_t* lo, size_t* hi) {
-  const size_t base = n / (size_t)w, rem = n % (size_t)w;
-  *lo = (size_t)r * base + std::min<size_t>((size_t)r, rem);
-  *hi = *lo + base + ((size_t)r < rem ? 1 : 0);
+static bool shard_allgather(const void* send, void* recv, size_t bytes) {
+  return pengk_comm_host_allgather(send, recv, bytes) == PENGK_OK;
+}
+
+void start_sharded_ingest() {
+  if (world() <= 1) return;
+  check(pengk_comm_host_init_env(), "pengk_comm_host_init_env");
+  SequenceShardComm sc;
+  sc.rank = rank();
+  sc.world = world();
+  sc.allgather = shard_allgather;
+  SequenceSet::setShardComm(sc);
+}
+
+void finish_ranks() {
+  if (!launched()) return;
+  uint64_t one = 1;
+  if (world() > 1) check(pengk_comm_host_allreduce_u64(&one, 1), "pengk_comm_host_allreduce_u64");  // nobody leaves early
+  if (g_ctx) check(pengk_comm_destroy(g_ctx), "pengk_comm_destroy");
+  pengk_comm_host_shutdown();
 }
 
 void check(int rc, const char* what) {
@@ -48,7 +65,6 @@ void check(int rc, const char* what) {
 // Context creation (HIP runtime start-up + code object load, ~0.2 s) can run beside the FASTA reader.
 static std::thread g_starter;
 static int g_starter_rc = PENGK_OK;
-static std::string g_starter_error;
 
 static void join_starter() {
   if (g_starter.joinable()) g_starter.join();
@@ -58,18 +74,18 @@ void start_context() {
   if (g_ctx || g_starter.joinable()) return;
   g_starter = std::thread([] {
     g_starter_rc = pengk_create(device_index(), &g_ctx);
-    if (g_starter_rc != PENGK_OK) g_starter_error = pengk_last_error();  // the message is thread local
+    if (g_starter_rc != PENGK_OK) {
+      // no usable gfx950 device: there is no CPU path, and no point in reading gigabytes of FASTA first
+      std::cerr << "Error: pengk_create failed: " << pengk_error_name(g_starter_rc) << ": " << pengk_last_error() << std::endl;
+      _exit(1);
+    }
   });
   atexit(join_starter);  // an exit() on a FASTA error must not tear the process down under a starting runtime
 }
 
 pengk_ctx* context() {
   if (g_starter.joinable()) {
-    g_starter.join();
-    if (g_starter_rc != PENGK_OK) {
-      std::cerr << "Error: pengk_create failed: " << pengk_error_name(g_starter_rc) << ": " << g_starter_error << std::endl;
-      exit(1);
-    }
+    g_starter.join();  // (a failed start has already ended the process)
   }
   if (!g_ctx) check(pengk_create(device_index(), &g_ctx), "pengk_create");
   static bool options_set = false;

@@ -25,8 +25,11 @@ void check(int rc, const char* what);
 int rank();
 int world();
 bool launched();  // WORLD_SIZE is set (even to 1): the run goes through the communicator
-// contiguous whole-record shard [lo, hi) of rank r: sizes differ by at most one
-void shard_range(size_t n, int r, int w, size_t* lo, size_t* hi);
+// world > 1: opens the host channel of the job (include/pengk.h) and makes the FASTA reader shard by it -- rank r
+// reads, translates and holds only its byte range of every input file.  Call before the first SequenceSet.
+void start_sharded_ingest();
+// launched runs: waits for every rank, then releases the communicator and the host channel (call before leaving)
+void finish_ranks();
 
 // PENGK_TIMING=1: wall-clock report of sub-phases on stderr (stdout stays the reference's trace)
 struct Lap {

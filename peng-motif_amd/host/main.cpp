@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
 #include "Global.h"
@@ -26,15 +27,24 @@ struct PhaseClock {
     last = now;
   }
   void total() {
-    if (on) std::cerr << "[timing] total: " << std::chrono::duration<double>(clk::now() - t0).count() << " s" << std::endl;
+    if (!on) return;
+    std::cerr << "[timing] total: " << std::chrono::duration<double>(clk::now() - t0).count() << " s" << std::endl;
+    // peak resident set of this process (a rank of a sharded run holds its part of the input only)
+    if (FILE* f = std::fopen("/proc/self/status", "r")) {
+      char line[256];
+      while (std::fgets(line, sizeof line, f))
+        if (std::strncmp(line, "VmHWM:", 6) == 0)
+          std::cerr << "[timing] peak resident memory: " << std::atof(line + 6) / 1024.0 << " MiB" << std::endl;
+      std::fclose(f);
+    }
   }
 };
 }  // namespace
 
 int main(int nargs, char** args) {
   PhaseClock clock;
-  // multi-GPU run (one process per GPU under a launcher): every rank reads the input and follows the same
-  // deterministic control flow on the all-reduced tables; rank 0 alone reports and writes
+  // multi-GPU run (one process per GPU under a launcher): every rank reads its byte range of the input, counts its
+  // shard and follows the same deterministic control flow on the all-reduced tables; rank 0 alone reports and writes
   if (pengk_host::rank() != 0 && !std::freopen("/dev/null", "w", stdout)) return 1;
   Global::init(nargs, args);
   clock.lap("read FASTA");
@@ -84,6 +94,8 @@ int main(int nargs, char** args) {
   // HIP context -- dies with it; walking it all to hand it back piece by piece cost a quarter of the whole run on a
   // 2 GB input (0.25 of 1.1 s).  The outputs are closed and flushed, the device is idle: leave.
   // (PENGK_FULL_TEARDOWN=1 keeps the orderly release, e.g. under a leak checker.)
+  pengk_host::check(pengk_synchronize(pengk_host::context()), "pengk_synchronize");
+  pengk_host::finish_ranks();
   if (std::getenv("PENGK_FULL_TEARDOWN")) {
     Global::destruct();
     pengk_host::shutdown();
@@ -91,7 +103,6 @@ int main(int nargs, char** args) {
     clock.total();
     return 0;
   }
-  pengk_host::check(pengk_synchronize(pengk_host::context()), "pengk_synchronize");
   clock.total();
   std::cout.flush();
   std::cerr.flush();

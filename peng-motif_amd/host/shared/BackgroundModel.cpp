@@ -29,7 +29,7 @@ BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vecto
   // count over the contiguous code buffer, split over host threads by sequence ranges
   const uint8_t* codes = sequenceSet.codes();
   const int64_t* offs = sequenceSet.offsets();
-  const size_t N = sequenceSet.getN();
+  const size_t N = sequenceSet.getLocalN();  // this rank's records; the counters are summed over the ranks below
   unsigned nt = std::thread::hardware_concurrency();
   if (nt == 0) nt = 1;
   if (nt > 32) nt = 32;
@@ -96,6 +96,8 @@ BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vecto
     for (int y = 0; y < 16; ++y) n_[1][y] += n2[y] + e[4 + y];
     for (int y = 0; y < 64; ++y) n_[2][y] += f[20 + y] + e[20 + y];
   }
+  // sharded ingest: the model is additive in its 84 counters (not in V)
+  for (int k = 0; k < 3; ++k) SequenceSet::allreduceSum(n_[k], (size_t)1 << (2 * (k + 1)));
   calculateV();
 }
 
@@ -106,16 +108,19 @@ BackgroundModel::~BackgroundModel() {
   }
 }
 
+// The reference keeps the counters and their sum in `int` (src/shared/BackgroundModel.cpp:492-495), which overflows
+// beyond 2^31 bases (BASELINE configs[3]: 2e10).  Here they are 64-bit and converted to float directly: bit-identical
+// to the reference while every counter fits an int, the intended arithmetic beyond (documented like the 64-bit scan
+// positions of the count; the device's pengk_bg_model does the same).
 void BackgroundModel::calculateV() {
-  int base_counts = 0;  // `int` like the reference
-  for (int y = 0; y < 4; ++y) base_counts += (int)n_[0][y];
-  for (int y = 0; y < 4; ++y)
-    v_[0][y] = ((float)(int)n_[0][y] + A_[0] * 0.25f) / ((float)base_counts + A_[0]);
+  long long base_counts = 0;
+  for (int y = 0; y < 4; ++y) base_counts += n_[0][y];
+  for (int y = 0; y < 4; ++y) v_[0][y] = ((float)n_[0][y] + A_[0] * 0.25f) / ((float)base_counts + A_[0]);
   for (int k = 1; k <= K_; ++k) {
     const int ny = 1 << (2 * (k + 1)), yk = 1 << (2 * k);
     for (int y = 0; y < ny; ++y) {
       const float prior = interpolate_ ? v_[k - 1][y % yk] : 0.25f;
-      v_[k][y] = ((float)(int)n_[k][y] + A_[k] * prior) / ((float)(int)n_[k - 1][y / 4] + A_[k]);
+      v_[k][y] = ((float)n_[k][y] + A_[k] * prior) / ((float)n_[k - 1][y / 4] + A_[k]);
     }
     for (int g = 0; g < ny; g += 4) {
       float factor = 0.0f;

@@ -57,22 +57,40 @@ void* default_init_allocator<T>::huge_alloc(std::size_t bytes) {
 template <class T>
 using raw_vector = std::vector<T, default_init_allocator<T>>;
 
+// Sharded ingest (multi-GPU runs, one process per GPU): rank r of `world` reads only its byte range of the file, cut at
+// record starts ('>' at the start of a line), and holds only those records.  What the reference derives from the whole
+// file -- N, min / max length, base frequencies, its warnings -- is combined over the ranks through `allgather`
+// (recv[r * bytes ...) = rank r's send[0 .. bytes); returns false when a rank is lost).  The reader itself stays free of
+// the device library: the CLI plugs the host channel of include/pengk.h in here (Global.cpp), tests plug in files.
+struct SequenceShardComm {
+  int rank = 0, world = 1;
+  bool (*allgather)(const void* send, void* recv, size_t bytes) = nullptr;
+};
+
 class SequenceSet {
  public:
   SequenceSet(std::string sequenceFilepath, bool single_stranded = false, std::string intensityFilepath = "");
   ~SequenceSet();
+
+  // process-wide; set before the first SequenceSet is constructed (default: one rank, the whole file)
+  static void setShardComm(const SequenceShardComm& comm);
+  static const SequenceShardComm& shardComm();
+  // sum over the ranks of n 64-bit counters (in place) through shardComm(); exits(1) when a rank is lost
+  static void allreduceSum(long long* values, size_t n);
 
   std::string getSequenceFilepath() { return path_; }
   // the warnings this set's constructor wrote to stderr (a caller that re-uses the set where the reference reads the
   // file again replays them)
   const std::string& diagnostics() const { return diagnostics_; }
   std::vector<Sequence*> getSequences();  // materialises views on first use
-  size_t getN() { return offs_.size() - 1; }
+  size_t getN() { return n_global_; }                 // records of the whole file (all ranks)
+  size_t getLocalN() { return offs_.size() - 1; }      // records this rank holds: codes() / offsets() / getSequences()
+  size_t getLocalBase() { return k_base_; }            // number of records in front of this rank's first one
   unsigned int getMinL() { return minL_; }
   unsigned int getMaxL() { return maxL_; }
   float* getBaseFrequencies() { return base_freq_; }
 
-  // contiguous representation: codes of record i are codes()[offsets()[i] .. offsets()[i+1])
+  // contiguous representation: codes of local record i are codes()[offsets()[i] .. offsets()[i+1])
   const uint8_t* codes() const { return codes_; }
   const int64_t* offsets() const { return offs_.data(); }
 
@@ -89,8 +107,9 @@ class SequenceSet {
   raw_vector<uint64_t> hdr_off_;
   std::string header(size_t k) const {
     const uint64_t b = hdr_off_[k], e = hdr_off_[k + 1];
-    return e == b ? std::to_string(k + 1) : std::string(hdr_pool_.data() + b, (size_t)(e - b));
+    return e == b ? std::to_string(k_base_ + k + 1) : std::string(hdr_pool_.data() + b, (size_t)(e - b));
   }
+  size_t n_global_ = 0, k_base_ = 0;
   std::vector<Sequence*> sequences_;
   bool materialised_ = false;
   unsigned int minL_, maxL_;

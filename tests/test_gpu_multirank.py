@@ -1,0 +1,144 @@
+"""The multi-rank peng_motif, rehearsed on ONE GPU: two (and three) CLI processes started with a launcher's environment,
+each reading only its byte range of the FASTA file (sharded ingest), counting its shard, summing {counts, ltot} and
+gathering the EM's PWMs -- with PENGK_COMM_TRANSPORT=tcp, the rehearsal transport that stages the tables through host
+memory over the host channel, because RCCL cannot put two ranks on one card.  Everything except the carrier of the sum
+is the code an 8-GPU run executes (BASELINE configs[3]: "seqs sharded 8x MI355X, all-reduce of the 4^W counts").
+
+Bar: stdout, MEME and JSON of rank 0 byte-identical to the plain single-process run; the other ranks print nothing on
+stdout; stderr warnings identical; per-rank resident memory ~ 1/world of the file.
+Reference for the single-process semantics: src/shared/SequenceSet.cpp:285-447, src/shared/BackgroundModel.cpp:60-84,
+src/base_pattern.cpp:382 (the non-overlap rule never crosses a sequence boundary: shard counts add exactly)."""
+import os
+import re
+import socket
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "peng-motif_amd", "host", "peng_motif")
+GOLD = os.path.join(ROOT, "tests", "golden")
+SYNTH = os.path.join(ROOT, "tools", "synth_fasta")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PENGK_COMM_TRANSPORT")}
+    env.update(extra)
+    return env
+
+
+def run_plain(args, tmp_path, tag="plain", timing=False):
+    meme, js = tmp_path / (tag + ".meme"), tmp_path / (tag + ".json")
+    env = clean_env(**({"PENGK_TIMING": "1"} if timing else {}))
+    r = subprocess.run([CLI] + args + ["-o", str(meme), "-j", str(js)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
+                       timeout=900)
+    return r.returncode, r.stdout, r.stderr, meme.read_bytes() if meme.exists() else None, js.read_bytes() if js.exists() else None
+
+
+def run_ranks(args, world, tmp_path, tag="ranks", timing=False, transport="tcp"):
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        meme, js = tmp_path / ("%s%d.meme" % (tag, rank)), tmp_path / ("%s%d.json" % (tag, rank))
+        env = clean_env(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                        PENGK_COMM_TRANSPORT=transport, PENGK_COMM_TIMEOUT="300")
+        if timing:
+            env["PENGK_TIMING"] = "1"
+        procs.append((subprocess.Popen([CLI] + args + ["-o", str(meme), "-j", str(js)], stdout=subprocess.PIPE,
+                                       stderr=subprocess.PIPE, env=env), meme, js))
+    out = []
+    for p, meme, js in procs:
+        so, se = p.communicate(timeout=900)
+        out.append((p.returncode, so, se, meme.read_bytes() if meme.exists() else None, js.read_bytes() if js.exists() else None))
+    return out
+
+
+def strip_timing(stderr):
+    return b"".join(l for l in stderr.splitlines(True) if not l.startswith(b"[timing]"))
+
+
+def peak_rss_mb(stderr):
+    m = re.search(rb"\[timing\] peak resident memory: ([0-9.]+) MiB", stderr)
+    assert m, stderr[-500:]
+    return float(m.group(1))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("args", [["MafK.fasta", "-w", "10"], ["MafK.fasta", "-w", "8", "--strand", "PLUS"],
+                                  ["torture.fa", "-w", "6"]], ids=["mafk_w10", "mafk_w8_plus", "torture_w6"])
+def test_ranks_on_one_gpu_print_what_one_process_prints(tmp_path, args, world):
+    args = [os.path.join(GOLD, args[0])] + args[1:]
+    rc, so, se, meme, js = run_plain(args, tmp_path)
+    assert rc == 0, se.decode()[-2000:]
+    res = run_ranks(args, world, tmp_path)
+    for rank, (rrc, rso, rse, rmeme, rjs) in enumerate(res):
+        assert rrc == 0, (rank, rse.decode()[-2000:])
+        if rank == 0:
+            assert rso == so and rmeme == meme and rjs == js
+            assert rse == se  # the reader's warnings, once, in file order
+        else:
+            assert rso == b"" and rmeme is None and rjs is None and rse == b""
+
+
+def test_ranks_with_a_separate_background_file(tmp_path):
+    args = [os.path.join(GOLD, "MafK_100seqs.fasta"), "-w", "8", "--background-sequences", os.path.join(GOLD, "MafK.fasta")]
+    rc, so, se, meme, js = run_plain(args, tmp_path)
+    assert rc == 0
+    res = run_ranks(args, 2, tmp_path)
+    assert [r[0] for r in res] == [0, 0], res[0][2].decode()[-1000:]
+    assert (res[0][1], res[0][3], res[0][4]) == (so, meme, js) and res[1][1] == b""
+
+
+def test_two_ranks_on_a_synthetic_set_and_their_memory(tmp_path):
+    """300 000 x 200 bp (63 MB of FASTA), W=10: outputs byte-identical, and a rank's peak resident memory grows with ITS
+    shard, not with the file -- measured as the difference to the same run on a tenth of the records."""
+    fa = str(tmp_path / "s300k.fa")
+    subprocess.check_call([SYNTH, fa, "300000", "200", "1", "0"])
+    small = str(tmp_path / "s30k.fa")
+    subprocess.check_call([SYNTH, small, "30000", "200", "1", "0"])
+    rc, so, se, meme, js = run_plain([fa, "-w", "10"], tmp_path, timing=True)
+    assert rc == 0, se.decode()[-2000:]
+    res = run_ranks([fa, "-w", "10"], 2, tmp_path, timing=True)
+    assert [r[0] for r in res] == [0, 0], res[0][2].decode()[-2000:]
+    assert (res[0][1], res[0][3], res[0][4]) == (so, meme, js)
+    assert strip_timing(res[0][2]) == strip_timing(se) and res[1][1] == b""
+    base = run_ranks([small, "-w", "10"], 2, tmp_path, tag="small", timing=True)
+    whole_small = run_plain([small, "-w", "10"], tmp_path, tag="plainsmall", timing=True)
+    grow_plain = peak_rss_mb(se) - peak_rss_mb(whole_small[2])
+    for rank in range(2):
+        grow = peak_rss_mb(res[rank][2]) - peak_rss_mb(base[rank][2])
+        # one process: file text + codes + packed stream for 270k more records; a rank: for 135k more
+        assert grow < 0.65 * grow_plain, (rank, grow, grow_plain)
+
+
+def test_a_fasta_error_in_one_shard_ends_every_rank(tmp_path):
+    fa = tmp_path / "bad.fa"
+    rng = np.random.default_rng(5)
+    recs = [">r%d\n%s\n" % (i, "".join(rng.choice(list("ACGT"), 80).tolist())) for i in range(400)]
+    recs[333] = ">r333\nACGT ACGT\n"
+    fa.write_text("".join(recs))
+    rc, so, se, _, _ = run_plain([str(fa), "-w", "6"], tmp_path)
+    assert rc == 1 and b"contains space character" in se
+    res = run_ranks([str(fa), "-w", "6"], 2, tmp_path)
+    assert [r[0] for r in res] == [1, 1]
+    assert res[0][2] == se and res[1][2] == b""
+
+
+def test_a_rank_that_never_arrives_is_an_error_not_a_hang(tmp_path):
+    port = free_port()
+    env = clean_env(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                    PENGK_COMM_TRANSPORT="tcp", PENGK_COMM_TIMEOUT="3")
+    r = subprocess.run([CLI, os.path.join(GOLD, "MafK_100seqs.fasta"), "-w", "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env, timeout=120)
+    assert r.returncode == 1 and b"only 1 of 2 ranks" in r.stderr

@@ -94,3 +94,100 @@ def test_seed_ranking_replays_std_sort():
     r = subprocess.run([os.path.join(host, "ranked_prefix_test")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stdout.decode()
     assert r.stdout.decode().startswith("ok ")
+
+
+# ---- sharded ingest: every rank reads only its byte range (multi-GPU CLI; replaces the whole-file pass of
+#      src/shared/SequenceSet.cpp:285-447 per rank) ---------------------------------------------------------------------
+def run_sharded(path, world, tmp_path):
+    """WORLD processes of host_ingest_dump, combining their shards through files (the stand-in for the host channel)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(DUMP), "host_ingest_dump"])
+    d = tmp_path / ("gather_w%d" % world)
+    d.mkdir()
+    procs = [subprocess.Popen([DUMP, path, str(r), str(world), str(d), str(d / ("codes%d" % r))], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    return [p.returncode for p in procs], outs, d
+
+
+def parse_dump(stdout):
+    out = stdout.decode().split("\n")
+    t = out[0].split()
+    return dict(zip(t[0::2], t[1::2])), out
+
+
+def ragged_fasta(tmp_path, n=6000, seed=11, tail=">last\nACGNNTRACGTAC\n"):
+    rng = np.random.default_rng(seed)
+    parts = ["\n\n"]  # blank lines in front of the first header are allowed
+    for i in range(n):
+        L = int(rng.integers(1, 300)) if i % 97 else int(rng.integers(3000, 9000))  # some records span several cuts
+        s = "".join(rng.choice(list("ACGTacgtN"), size=L, p=[.23, .23, .23, .23, .015, .015, .015, .015, .02]).tolist())
+        hdr = ">" if i % 311 == 0 else ">r%d > not a header" % i
+        parts.append(hdr + "\n" + "\n".join(s[j:j + 60] for j in range(0, L, 60)) + "\n")
+        if i % 700 == 3:
+            parts.append(">empty%d\n" % i)
+    parts.append(tail)
+    p = tmp_path / "ragged.fa"
+    p.write_text("".join(parts))
+    return str(p)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_ingest_equals_the_whole_file_reader(tmp_path, world):
+    path = ragged_fasta(tmp_path)
+    whole = subprocess.run([DUMP, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert whole.returncode == 0
+    head0, out0 = parse_dump(whole.stdout)
+    rcs, outs, d = run_sharded(path, world, tmp_path)
+    assert rcs == [0] * world, [o[1].decode()[-300:] for o in outs]
+    codes, offs = po.read_fasta(path)
+    got_codes, got_lens, base = [], [], 0
+    for r, (so, se) in enumerate(outs):
+        head, out = parse_dump(so)
+        # global quantities are the whole file's on every rank: N, min / max length, base frequencies, counters, V
+        for key in ("N", "minL", "maxL", "f0", "f1", "f2", "f3"):
+            assert head[key] == head0[key], (r, key)
+        assert out[1] == out0[1] and out[2] == out0[2]
+        assert int(head["base"]) == base
+        base += int(head["localN"])
+        got_codes.append(np.fromfile(str(d / ("codes%d" % r)), np.uint8))
+        got_lens.append(np.diff(np.fromfile(str(d / ("codes%d.offs" % r)), np.int64)))
+        # rank 0 alone speaks for the file, with the single reader's words
+        assert se == (whole.stderr if r == 0 else b"")
+    assert base == int(head0["N"]) == len(offs) - 1
+    assert np.array_equal(np.concatenate(got_codes), codes)
+    assert np.array_equal(np.concatenate(got_lens), np.diff(offs))
+    assert whole.stderr.count(b"undefined base") == 3 and whole.stderr.count(b"without sequence") == 9
+
+
+def test_sharded_ingest_names_an_unnamed_last_record_by_its_global_index(tmp_path):
+    path = ragged_fasta(tmp_path, n=500, tail=">\nACGTNACGT\n")
+    whole = subprocess.run([DUMP, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    rcs, outs, _ = run_sharded(path, 4, tmp_path)
+    assert rcs == [0] * 4 and outs[0][1] == whole.stderr
+    assert b"undefined base: N at sequence 501" in whole.stderr
+
+
+def test_sharded_ingest_with_more_ranks_than_records(tmp_path):
+    p = tmp_path / "tiny.fa"
+    p.write_text(">a\nACGTACGTAC\n>b\nGGGTTTAAAC\nCC")  # unterminated last line: dropped by the reader
+    whole = subprocess.run([DUMP, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    head0, out0 = parse_dump(whole.stdout)
+    rcs, outs, _ = run_sharded(str(p), 5, tmp_path)
+    assert rcs == [0] * 5
+    total = 0
+    for so, _ in outs:
+        head, out = parse_dump(so)
+        assert head["N"] == head0["N"] == "2" and out[1:3] == out0[1:3]
+        total += int(head["localN"])
+    assert total == 2
+
+
+@pytest.mark.parametrize("text", [">a\nACGT\n" * 50 + ">b\nAC GT\n" + ">c\nACGT\n" * 50, "ACGT\n" + ">a\nACGT\n" * 100])
+def test_sharded_ingest_errors_end_every_rank(tmp_path, text):
+    """A format error in one rank's shard is every rank's error, reported once by rank 0 (the reference: exit(1))."""
+    p = tmp_path / "bad.fa"
+    p.write_text(text)
+    whole = subprocess.run([DUMP, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    rcs, outs, _ = run_sharded(str(p), 3, tmp_path)
+    assert whole.returncode == 1 and rcs == [1, 1, 1]
+    assert outs[0][1] == whole.stderr and outs[1][1] == outs[2][1] == b""
