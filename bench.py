@@ -58,6 +58,8 @@ def parse_args():
                     help="pengk option em_fast inside the step: 2 = serial bit-exact (the CLI's mode), 1 = one reciprocal per weight, 0 = reference terms")
     ap.add_argument("--em-stress-pwms", type=int, default=1000,
                     help="BASELINE configs[4]: EM-only stress on this many top-count seeds of the PLUS table (split over ranks); 0 = skip")
+    ap.add_argument("--em-table-budget-mb", type=int, default=0,
+                    help="pengk option em_table_budget_mb: weight tables per batch of PWMs in the serial EM mode (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end peng_motif CLI run on the config's FASTA")
     ap.add_argument("--count-impl", type=int, default=0, help="0 auto, 1 direct atomics, 2 partitioned")
@@ -81,6 +83,21 @@ def relaunch_under_torchrun(args):
 
 def sha(t):
     return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()
+
+
+def config_key(nseq, L, W, both):
+    return "W%d_n%d_L%d_%s" % (W, nseq, L, "BOTH" if both else "PLUS")
+
+
+def baseline_config_name(nseq, L, W, both):
+    """Which BASELINE.json config a size is -- only the sizes BASELINE.json names get its label."""
+    if (nseq, L, W, both) == (10_000_000, 200, 10, True):
+        return "BASELINE configs[2]"
+    if (nseq, L, W, both) == (12_500_000, 200, 12, True):
+        return "one of the 8 shards of BASELINE configs[3]"
+    if (nseq, L, W, both) == (10_000_000, 200, 10, False):
+        return "the PLUS table of BASELINE configs[4]"
+    return "not a BASELINE.json configuration"
 
 
 def main():
@@ -137,6 +154,7 @@ def main():
     pk._check(lib.pengk_set_stream(ctx.h, ctx_stream.cuda_stream))  # kernels + the exchange share one stream
     ctx.set_option("count_impl", args.count_impl)
     ctx.set_option("em_fast", args.em_fast)
+    ctx.set_option("em_table_budget_mb", args.em_table_budget_mb)
 
     import ctypes as C
     rccl_ranks = 0
@@ -394,8 +412,8 @@ def main():
             "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 counts / f32 scores / f32 serial EM sums (f64 tree sums in the throughput EM mode)", "data": "synthetic",
-            "config": {"workload": "synthetic %dx%d bp per GPU, W=%d, %s strands, bg-order 2 (BASELINE configs[2]); step = count + all-reduce + sweep + EM(%d PWMs x %d it)"
-                       % (nseq, L, W, "both" if both else "plus", P_total, args.em_iters),
+            "config": {"workload": "synthetic %dx%d bp per GPU, W=%d, %s strands, bg-order 2 (%s); step = count + all-reduce + sweep + EM(%d PWMs x %d it)"
+                       % (nseq, L, W, "both" if both else "plus", baseline_config_name(nseq, L, W, both), P_total, args.em_iters),
                        "n_seq_per_gpu": nseq, "seq_len": L, "W": W, "strand": args.strand, "ltot_global": ltot,
                        "parallelism": "sequence shards x%d, one all-reduce of the 4^W counts" % world,
                        "exchange": ("RCCL, %d rank(s), pengk_allreduce_tables on the kernels' stream" % rccl_ranks) if rccl_ranks
@@ -434,16 +452,20 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         # HBM traffic and issue counters are NOT measured in this run (they need rocprofv3 --pmc passes): copied from the
-        # committed profile, with the commit and the configuration they were taken at
-        prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        # committed profile OF THIS CONFIGURATION (profiles/traffic_by_config.json, one entry per W / size / strand mode,
+        # stamped with its commit); a configuration nobody profiled carries no traffic figure
+        prof = os.path.join(ROOT, "profiles", "traffic_by_config.json")
         if os.path.exists(prof):
             try:
-                pj = json.load(open(prof))
-                out["roofline"]["traffic"] = pj.get("count_kernel_hbm_bytes_per_launch")
-                out["roofline"]["traffic_source"] = "profiles/traffic_latest.json: rocprofv3 --pmc passes at commit %s (%s), not this run" % (
-                    pj.get("commit", "?"), pj.get("config", "config 3"))
-                if "issue" in pj:  # second roofline of K1: the pass-A kernel is bound by instruction issue, not by bytes
-                    out["roofline_issue"] = pj["issue"]
+                pj = json.load(open(prof)).get(config_key(nseq, L, W, both))
+                if pj:
+                    out["roofline"]["traffic"] = pj.get("count_kernel_hbm_bytes_per_launch")
+                    out["roofline"]["traffic_source"] = "profiles/traffic_by_config.json[%s]: rocprofv3 --pmc passes at commit %s, not this run" % (
+                        config_key(nseq, L, W, both), pj.get("commit", "?"))
+                    if "issue" in pj:  # second roofline of K1: the pass-A kernel is bound by instruction issue, not by bytes
+                        out["roofline_issue"] = pj["issue"]
+                else:
+                    out["roofline"]["traffic_source"] = "no committed --pmc profile for %s" % config_key(nseq, L, W, both)
             except Exception:
                 pass
         if em_stress and em_stress[1]:
@@ -455,12 +477,24 @@ def main():
                 "frac": round(evals * (2 * W + 4) / 1e12 / FP32_VECTOR_PEAK_TF, 5),
                 "table_stream_gb_per_s": round(evals * 8 / 1e9, 1), "table_stream_frac_of_hbm_peak": round(evals * 8 / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "8 B per evaluation (u32 count + f32 background) streamed per PWM from L2 / Infinity Cache (the 8 MB of tables stay on die), so the byte rate may exceed the HBM peak; 2W+4 flop per evaluation as SURVEY.md 8(d) counts them"}
+            if em_stress[2]:
+                # the mode the CLI ships and the bench step times: pinned to the reference's PWMs bit for bit
+                ev_s = em_stress[0] * args.em_iters * NP / (em_stress[2] * 1e-3)
+                out["roofline_em"]["parity_mode"] = {
+                    "kernel": "em_weights_kernel<%d> + em_fold_scan_kernel<%d> (K5, serial bit-exact mode, same PWMs)" % (W, W),
+                    "ms": round(em_stress[2], 4), "evals_per_s": round(ev_s, 1),
+                    "achieved": round(ev_s * (2 * W + 4) / 1e12, 3), "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(ev_s * (2 * W + 4) / 1e12 / FP32_VECTOR_PEAK_TF, 5),
+                    "note": "reference-parity mode: every cell's 4^(W-1) float32 additions in the reference's order (as a wave-wide scan); the throughput mode above is pinned to the fp64 oracle within 1e-5, not to the reference's own rounding"}
         if checks:
             out["checks"] = checks
-        if world == 1 and not args.no_e2e:
-            out["components"]["e2e_cli"] = e2e_cli(args, W, both, L, nseq)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, W, both, L, stress_probe)
+        if world == 1 and not args.no_e2e:
+            out["components"]["e2e_cli"] = e2e_cli(args, W, both, L, nseq, out.get("cpu_baseline"))
+            ref_full = out["components"]["e2e_cli"].get("reference_same_box")
+            if ref_full is not None and "cpu_baseline" in out:
+                out["cpu_baseline"]["reference_full_size"] = ref_full
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     ctx.close()
@@ -468,10 +502,61 @@ def main():
         dist.destroy_process_group()
 
 
-def e2e_cli(args, W, both, L, nseq):
+def mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def reference_same_box(fa, tmp, W, both, L, nseq, our_wall, cpu_base):
+    """The compiled reference CLI (oracle/_ref/peng_motif_ref, its default --threads 1) on the SAME full-size FASTA, on this
+    box's host cores, in this run: the denominator north_star asks for.  Skipped -- with the reason -- when the binary did
+    not travel, when the box has too little free memory (the reference keeps ~12 bytes per base) or when the
+    300k-sequence sample of cpu_baseline extrapolates to more than 300 s."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "peng_motif_ref")
+    if not os.path.exists(exe):
+        return {"skipped": "oracle/_ref/peng_motif_ref not present on this box"}
+    need_gb = max(48.0, nseq * L * 14 / 1e9)
+    if mem_available_gb() < need_gb:
+        return {"skipped": "%.0f GB of host memory available, the reference needs about %.0f GB at this size" % (mem_available_gb(), need_gb)}
+    est = None
+    try:
+        ph = cpu_base["reference_cli_phases"]["threads_1"]
+        n_s = int(cpu_base["reference_cli_sample"].split(" on ")[1].split(" x ")[0])
+        est = ph["total"] * nseq / n_s
+    except Exception:  # noqa: BLE001 -- no sample: run with the time limit alone
+        pass
+    if est is not None and est > 300.0:
+        return {"skipped": "the sample extrapolates to %.0f s (> 300 s)" % est, "extrapolated_s": round(est, 1)}
+    meme = os.path.join(tmp, "ref.meme")
+    cmd = [exe, fa, "-w", str(W), "--strand", "BOTH" if both else "PLUS", "--threads", "1", "-o", meme]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    except subprocess.TimeoutExpired:
+        return {"skipped": "the reference did not finish within 600 s", "extrapolated_s": round(est, 1) if est else None}
+    wall = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"skipped": "the reference exited with %d" % r.returncode}
+    same = None
+    ours = os.path.join(tmp, "o.meme")
+    if os.path.exists(ours) and os.path.exists(meme):
+        same = open(ours, "rb").read() == open(meme, "rb").read()
+    return {"reference_wall_s_same_box": round(wall, 2), "speedup_same_box": round(wall / our_wall, 1), "threads": 1,
+            "host_cores": os.cpu_count(), "extrapolated_from_sample_s": round(est, 1) if est else None,
+            "meme_identical_to_reference": same,
+            "command": "oracle/_ref/peng_motif_ref s.fa -w %d --strand %s --threads 1 -o ref.meme (same file, same box, same run)" % (W, "BOTH" if both else "PLUS")}
+
+
+def e2e_cli(args, W, both, L, nseq, cpu_base=None):
     """End to end: the config's FASTA on disk -> peng-motif_amd/host/peng_motif (PENGK_TIMING=1) -> MEME + JSON, wall clock
-    of the process and the phases it reports, beside BASELINE.md's figure for the reference (277.3 s at 10M x 200 bp, W=10,
-    1 thread, survey container)."""
+    of the process and the phases it reports; then the compiled reference on the same file on this box
+    (reference_same_box).  BASELINE.md's 277.3 s (10M x 200 bp, W=10, 1 thread) was measured in the survey container, on
+    another machine: it is kept as context and labelled so."""
     exe = os.path.join(ROOT, "peng-motif_amd", "host", "peng_motif")
     gen = os.path.join(ROOT, "tools", "synth_fasta")
     if not (os.path.exists(exe) and os.path.exists(gen)):
@@ -503,10 +588,15 @@ def e2e_cli(args, W, both, L, nseq):
             if best is None or wall < best[0]:
                 best = (wall, phases)
         n_motifs = sum(1 for l in open(os.path.join(tmp, "o.meme")) if l.startswith("MOTIF"))
-        return {"wall_s": round(best[0], 3), "phases_s": best[1], "motifs": n_motifs, "fasta_bytes": os.path.getsize(fa),
-                "fasta_generation_s": round(t_gen, 2), "command": "peng_motif s.fa -w %d --strand %s -o o.meme -j o.json" % (W, "BOTH" if both else "PLUS"),
-                "reference_wall_s_baseline_md": 277.3 if (nseq, L, W, both) == (10_000_000, 200, 10, True) else None,
-                "speedup_vs_baseline_md": round(277.3 / best[0], 1) if (nseq, L, W, both) == (10_000_000, 200, 10, True) else None}
+        is_c2 = (nseq, L, W, both) == (10_000_000, 200, 10, True)
+        res = {"wall_s": round(best[0], 3), "phases_s": best[1], "motifs": n_motifs, "fasta_bytes": os.path.getsize(fa),
+               "fasta_generation_s": round(t_gen, 2), "command": "peng_motif s.fa -w %d --strand %s -o o.meme -j o.json" % (W, "BOTH" if both else "PLUS"),
+               # context only: a different machine (the survey container), NOT a same-box ratio
+               "reference_wall_s_baseline_md_other_machine": 277.3 if is_c2 else None,
+               "cross_machine_ratio_vs_baseline_md": round(277.3 / best[0], 1) if is_c2 else None}
+        if not args.no_cpu_baseline:
+            res["reference_same_box"] = reference_same_box(fa, tmp, W, both, L, nseq, best[0], cpu_base)
+        return res
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -149,6 +149,11 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     ctx->em_serial_scan = (int)value;
     return PENGK_OK;
   }
+  if (strcmp(name, "em_table_budget_mb") == 0) {
+    if (value < 0) return fail(PENGK_ERR_ARG, "em_table_budget_mb must be >= 0 (0 = automatic)");
+    ctx->em_table_budget_mb = (uint64_t)value;
+    return PENGK_OK;
+  }
   if (strcmp(name, "iupac_group_bytes") == 0) {
     ctx->iupac_group_bytes = (uint64_t)value;
     return PENGK_OK;

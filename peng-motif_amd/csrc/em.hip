@@ -562,7 +562,10 @@ __global__ __launch_bounds__(seqsum::CHAIN_THREADS) void em_fold_scan_kernel(con
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t cell = slot % (4u * W), pw = (lin & 7u) + 8u * (slot / (4u * W));
   if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
-  __shared__ __attribute__((aligned(16))) float lds[seqsum::CHAIN_LDS_FLOATS];
+#ifndef PENGK_SCAN_LDS_PAD
+#define PENGK_SCAN_LDS_PAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) float lds[seqsum::CHAIN_LDS_FLOATS + PENGK_SCAN_LDS_PAD];
   constexpr uint32_t NP = 1u << (2 * W);
   const float* w = wbuf + (size_t)pw * 2u * NP;
   // position 0 reads the weights kernel's second copy, where its four cells lie like those of position W-1
@@ -692,6 +695,9 @@ namespace pengk {
 namespace {
 #endif
 
+#ifndef PENGK_EM_BUDGET_GIB
+#define PENGK_EM_BUDGET_GIB 24
+#endif
 template <int W>
 int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
                   const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
@@ -702,7 +708,25 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
                      max_it, d_state, d_change);
   PENGK_HIP(hipGetLastError());
   const size_t np = (size_t)1 << (2 * W);
-  const size_t budget = (size_t)1 << 30;  // weight tables of one batch of PWMs
+  // Weight tables of one batch of PWMs (4^W floats per PWM, twice that with the scan's permuted copy: 8 MiB at W = 10,
+  // 128 MiB at W = 12); a batch is one launch per kernel and iteration.  Option "em_table_budget_mb" (0 = automatic):
+  //  * tables of up to 16 MiB per PWM (W <= 10): 192 MiB per batch, so that what the weights kernel writes is still in
+  //    the 256 MiB Infinity Cache when the scan reads it W times (1000 PWMs x 10 iterations at W = 10: 48.6 ms; with
+  //    1 GiB batches 58 ms, with all PWMs in one batch 79 ms: the scan is bound by its table reads, not by arithmetic;
+  //    profiles/r03_em_budget.log);
+  //  * larger tables never fit: one batch for the whole call (a quarter of the free memory at most), i.e. one launch
+  //    per kernel and iteration -- the scan then streams 12 x 64 MiB per PWM and iteration from HBM at W = 12.
+  size_t budget = (size_t)ctx->em_table_budget_mb << 20;
+  if (budget == 0) {
+    if (2 * np * sizeof(float) <= ((size_t)16 << 20)) {
+      budget = (size_t)192 << 20;
+    } else {
+      size_t free_b = 0, total_b = 0;
+      budget = (size_t)1 << 30;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        budget = std::min(std::max(budget, (free_b + ctx->em_tables_bytes) / 4), (size_t)PENGK_EM_BUDGET_GIB << 30);
+    }
+  }
   constexpr bool SCAN = (1u << (2 * W - 2)) >= 4u * seqsum::BLOCK;
   const bool scan = SCAN && ctx->em_serial_scan != 0;
   const size_t pwm_stride = scan ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)

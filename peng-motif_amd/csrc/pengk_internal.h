@@ -39,6 +39,7 @@ struct pengk_ctx {
   uint64_t n_windows_hint = 0;  // total windows of the attached items (0 = unknown: n_items * item_windows)
   uint64_t key_cap_override = 0; // test hook: entries per bucket region (0 = sized from the window count)
   uint64_t iupac_group_bytes = 0; // test hook: scratch budget of one group of large K4 patterns (0 = 1 GiB)
+  uint64_t em_table_budget_mb = 0; // K5 serial mode: MiB of weight tables per batch of PWMs (0 = automatic)
   int em_serial_scan = 1;       // K5 serial mode: 1 = cells summed by the parallel scan of seqsum.h, 0 = by dependent additions
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms

@@ -100,24 +100,38 @@ struct Row {
     asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
                  "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]));
   }
+  // Rounded float32 additions, x <- fl(x + t), written as the instructions themselves, sixteen terms per statement:
+  // left to the optimiser the two chains of run2 become v_pk_add_f32 on (t, t) pairs -- 128 register copies per block to
+  // build the pairs, half-rate packed additions, twice the registers (206 instead of ~100: two waves per SIMD instead of
+  // four); and one statement per addition makes the hazard recogniser put an s_nop behind every one of them.
+#define PENGK_ADD2(T) "v_add_f32 %0, " T ", %0\n\tv_add_f32 %1, " T ", %1\n\t"
+#define PENGK_ADD1(T) "v_add_f32 %0, " T ", %0\n\t"
+  static __device__ __forceinline__ void add16x2(float& x0, float& x1, const f4& a, const f4& b, const f4& c, const f4& d) {
+    asm(PENGK_ADD2("%2") PENGK_ADD2("%3") PENGK_ADD2("%4") PENGK_ADD2("%5") PENGK_ADD2("%6") PENGK_ADD2("%7") PENGK_ADD2("%8")
+        PENGK_ADD2("%9") PENGK_ADD2("%10") PENGK_ADD2("%11") PENGK_ADD2("%12") PENGK_ADD2("%13") PENGK_ADD2("%14")
+        PENGK_ADD2("%15") PENGK_ADD2("%16") PENGK_ADD2("%17")
+        : "+v"(x0), "+v"(x1)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+          "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+  }
+  static __device__ __forceinline__ void add16(float& x, const f4& a, const f4& b, const f4& c, const f4& d) {
+    asm(PENGK_ADD1("%1") PENGK_ADD1("%2") PENGK_ADD1("%3") PENGK_ADD1("%4") PENGK_ADD1("%5") PENGK_ADD1("%6") PENGK_ADD1("%7")
+        PENGK_ADD1("%8") PENGK_ADD1("%9") PENGK_ADD1("%10") PENGK_ADD1("%11") PENGK_ADD1("%12") PENGK_ADD1("%13")
+        PENGK_ADD1("%14") PENGK_ADD1("%15") PENGK_ADD1("%16")
+        : "+v"(x)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+          "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+  }
+#undef PENGK_ADD2
+#undef PENGK_ADD1
   // the terms added in order to two running values / to one
   __device__ __forceinline__ void run2(float& x0, float& x1) const {
 #pragma unroll
-    for (uint32_t j = 0; j < SEG / 4u; ++j) {
-      x0 += q[j].x; x1 += q[j].x;
-      x0 += q[j].y; x1 += q[j].y;
-      x0 += q[j].z; x1 += q[j].z;
-      x0 += q[j].w; x1 += q[j].w;
-    }
+    for (uint32_t j = 0; j < SEG / 4u; j += 4u) add16x2(x0, x1, q[j], q[j + 1u], q[j + 2u], q[j + 3u]);
   }
   __device__ __forceinline__ float run1(float x) const {
 #pragma unroll
-    for (uint32_t j = 0; j < SEG / 4u; ++j) {
-      x += q[j].x;
-      x += q[j].y;
-      x += q[j].z;
-      x += q[j].w;
-    }
+    for (uint32_t j = 0; j < SEG / 4u; j += 4u) add16(x, q[j], q[j + 1u], q[j + 2u], q[j + 3u]);
     return x;
   }
 };
@@ -131,23 +145,18 @@ __device__ __forceinline__ float lane_value(float v, int l) {  // wave-uniform
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// One block: lds holds 64 rows of 64 terms (row l = terms 64 l .. 64 l + 63 of the block); s = the sum in front of
-// the block.  Returns the sum behind it.  Wave-uniform.
+// One block: `mine` holds this lane's row of 64 terms (row l = terms 64 l .. 64 l + 63 of the block); s = the sum in
+// front of the block.  Returns the sum behind it.  Wave-uniform.
 //
 // Every lane evaluates its row from the two bases; an inclusive prefix composition (four DPP steps inside the rows of
 // 16 lanes, the three row boundaries with wave-uniform values) gives every lane the sum behind its row, valid if nothing
 // left the binade up to there.  No lane flagged: lane 63 holds the result.  Otherwise the first flagged row is added
 // the reference's way and the rows behind it are evaluated again in the new binade.
-__device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, float s, Stats& st) {
+// The block lives in registers for the whole call -- LDS is not touched, so the fetching wave may overwrite the
+// buffer with the next block while this one is evaluated (fold_chain).
+__device__ __forceinline__ float fold_block(const Row& mine, uint32_t lane, float s, Stats& st) {
   uint32_t first = 0;  // rows < first are already part of s
   for (;;) {
-    // (the row is read again after a crossing rather than kept: with the crossing row's registers beside it the kernel
-    // would need more than a third of a SIMD's registers, and three waves per chain could not all be resident)
-    const unsigned long long k0 = PENGK_CLOCK();
-    Row mine;
-    mine.read(lds + lane * SEG_STRIDE);
-    const unsigned long long k1 = PENGK_CLOCK();
-    PENGK_STAT_ADD(4, k1 - k0);
     PENGK_STAT_ADD(1, 1);
     const unsigned long long k2 = PENGK_CLOCK();
     if (bits(s) >= INF_BITS) return s;  // +inf + t = +inf
@@ -209,9 +218,9 @@ __device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, flo
     const int L = __builtin_ctzll(flagged);
     float v = s;
     if (L > 0) v = lane_value(end, L - 1);
-    Row crossing;
-    crossing.read(lds + (uint32_t)L * SEG_STRIDE);
-    s = crossing.run1(v);  // the reference's own additions through row L, all lanes alike
+    // the reference's own additions through row L from the exact value in front of it: every lane adds ITS row to v,
+    // lane L's result is the one that counts (no second copy of a row, no LDS)
+    s = lane_value(mine.run1(v), L);
     first = (uint32_t)L + 1u;
 #ifdef PENGK_SEQSUM_STATS
     asm volatile("" : "+v"(s));
@@ -226,63 +235,73 @@ __device__ __forceinline__ float fold_block(const float* lds, uint32_t lane, flo
 //
 // 1 + FETCH_WAVES waves per chain (a workgroup of CHAIN_THREADS threads, every thread calls fold_chain): moving a
 // block through a wave -- sixteen 16-byte loads, sixteen LDS writes, the wait for them -- takes as long as evaluating
-// it, so the waves behind wave 0 only fetch, 1 / FETCH_WAVES of a block each (block i into buffer i & 1, the loads of
-// block i + 1 in flight), while wave 0 only evaluates (block i - 1 from the other buffer); one workgroup barrier per
-// block.  The result is returned in wave 0 (the others return 0).
+// it, so the waves behind wave 0 only fetch, 1 / FETCH_WAVES of a block each, while wave 0 only evaluates.
+// ONE row buffer in LDS (17 KiB: eight chains per CU, two evaluating waves per SIMD that fill each other's waits):
+//   barrier B(i)   block i is in LDS            wave 0 reads its rows into registers (the whole block: 64 x 64 terms)
+//   barrier A(i)   block i is in registers      the fetchers deposit block i + 1 (its loads were issued during block
+//                                               i - 1) while wave 0 evaluates block i from registers
+// The result is returned in wave 0 (the others return 0).
 // CHECK: the fetching waves look at every term; a chain with a negative / non-finite term is summed by the plain loop
-// `serial`.
+// `serial`.  The flag is written in front of B(i) and read by every wave between B(i) and A(i); the next write comes
+// behind A(i): all waves leave at the same i.
 #ifndef PENGK_FETCH_WAVES
 #define PENGK_FETCH_WAVES 1  // measured (16 PWMs x 10 iterations, W = 10): 1 -> 1.02 ms, 2 -> 1.09, 4 -> 1.11
 #endif
 constexpr uint32_t FETCH_WAVES = PENGK_FETCH_WAVES;  // each fetches 1 / FETCH_WAVES of every block
 constexpr uint32_t CHAIN_THREADS = 64u * (1u + FETCH_WAVES);
-constexpr uint32_t CHAIN_LDS_FLOATS = 2u * LDS_FLOATS + 4u;  // two row buffers + the flag word
+constexpr uint32_t CHAIN_LDS_FLOATS = LDS_FLOATS + 4u;  // the row buffer + the flag word
 template <class Source, bool CHECK>
 __device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks, float* lds, uint32_t thread) {
   const uint32_t lane = thread & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(thread >> 6));  // wave-uniform
   const bool fetcher = wave != 0u;
   const uint32_t part = wave - 1u;  // which share of a block this fetch wave moves
-  volatile uint32_t* bad = reinterpret_cast<volatile uint32_t*>(lds + 2u * LDS_FLOATS);
+  volatile uint32_t* bad = reinterpret_cast<volatile uint32_t*>(lds + LDS_FLOATS);
   if (CHECK) {
     if (thread == 0) *bad = 0u;
     __syncthreads();
   }
   Stats st;
   float s = 0.0f;
+  bool fallback = false;
   if (fetcher) {
     float R[64 / FETCH_WAVES];
     src.template load<FETCH_WAVES>(0u, part, lane, R);
 #pragma unroll 1
-    for (uint32_t i = 0; i <= n_blocks; ++i) {
-      if (i < n_blocks) {
-        if (CHECK) {
-          uint32_t m = 0;
+    for (uint32_t i = 0; i < n_blocks; ++i) {
+      if (CHECK) {
+        uint32_t m = 0;
 #pragma unroll
-          for (int k = 0; k < (int)(64 / FETCH_WAVES); ++k) m = max(m, bits(R[k]));
-          if (__builtin_amdgcn_ballot_w64(m > 0x7F7FFFFFu) && lane == 0) *bad = 1u;
-        }
-        const unsigned long long c0 = PENGK_CLOCK();
-        src.template deposit<FETCH_WAVES>(part, lane, R, lds + (i & 1u) * LDS_FLOATS);
-        if (i + 1u < n_blocks) src.template load<FETCH_WAVES>(i + 1u, part, lane, R);
-        PENGK_STAT_ADD(2, PENGK_CLOCK() - c0);
+        for (int k = 0; k < (int)(64 / FETCH_WAVES); ++k) m = max(m, bits(R[k]));
+        if (__builtin_amdgcn_ballot_w64(m > 0x7F7FFFFFu) && lane == 0) *bad = 1u;
       }
-      __syncthreads();
-      if (CHECK && *bad) break;  // (both waves read the flag behind the same barrier)
+      const unsigned long long c0 = PENGK_CLOCK();
+      src.template deposit<FETCH_WAVES>(part, lane, R, lds);
+      if (i + 1u < n_blocks) src.template load<FETCH_WAVES>(i + 1u, part, lane, R);
+      PENGK_STAT_ADD(2, PENGK_CLOCK() - c0);
+      __syncthreads();  // B(i)
+      if (CHECK && *bad) break;
+      __syncthreads();  // A(i)
     }
   } else {
 #pragma unroll 1
-    for (uint32_t i = 0; i <= n_blocks; ++i) {
-      if (i > 0u) {
-        const unsigned long long c0 = PENGK_CLOCK();
-        s = fold_block(lds + ((i - 1u) & 1u) * LDS_FLOATS, lane, s, st);
-        PENGK_STAT_ADD(0, 1);
-        PENGK_STAT_ADD(3, PENGK_CLOCK() - c0);
+    for (uint32_t i = 0; i < n_blocks; ++i) {
+      __syncthreads();  // B(i)
+      if (CHECK && *bad) {
+        fallback = true;
+        break;
       }
-      __syncthreads();
-      if (CHECK && *bad) break;
+      const unsigned long long k0 = PENGK_CLOCK();
+      Row mine;
+      mine.read(lds + lane * SEG_STRIDE);
+      PENGK_STAT_ADD(4, PENGK_CLOCK() - k0);
+      __syncthreads();  // A(i)
+      const unsigned long long c0 = PENGK_CLOCK();
+      s = fold_block(mine, lane, s, st);
+      PENGK_STAT_ADD(0, 1);
+      PENGK_STAT_ADD(3, PENGK_CLOCK() - c0);
     }
-    if (CHECK && *bad) s = src.serial();
+    if (CHECK && fallback) s = src.serial();
   }
   st.flush(lane);
   return fetcher ? 0.0f : s;

@@ -35,7 +35,7 @@ struct PlainTerms {
   }
 };
 
-__global__ __launch_bounds__(seqsum::CHAIN_THREADS) void sequential_sum_kernel(const float* __restrict__ terms, uint64_t chain_len,
+__global__ __launch_bounds__(seqsum::CHAIN_THREADS, 4) void sequential_sum_kernel(const float* __restrict__ terms, uint64_t chain_len,
                                                                                 float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float lds[seqsum::CHAIN_LDS_FLOATS];
   const PlainTerms src{terms + (size_t)blockIdx.x * chain_len, chain_len};

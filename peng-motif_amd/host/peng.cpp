@@ -144,7 +144,15 @@ void Peng::filter_redundancy(const float merge_bit_factor_threshold, std::vector
 // could win is among them: decisions, printed motifs and scores are unchanged.
 namespace {
 constexpr size_t MERGE_GRID_MIN = 96;
-constexpr float MERGE_MARGIN = 2e-3f;  // >> 3 sums x 56 terms x half a float ulp at |s| <= 32 (2e-4)
+// Margin around the device maximum within which a pair is evaluated exactly.  For motifs of up to 14 columns
+// (the default max_merged_length): >> 3 sums x 56 terms x half a float ulp at |s| <= 32 (2e-4).  The reference's
+// float-rounded sums have 4 L terms of magnitude up to ~2 L, so the bound grows with L^2: the margin is scaled by
+// (L / 14)^2 for longer motifs (--max_merged_length up to PENGK_MAX_MOTIF_LEN = 64 columns: 0.042).
+constexpr float MERGE_MARGIN = 2e-3f;
+inline float merge_margin(size_t longest) {
+  const float r = longest > 14 ? (float)longest / 14.0f : 1.0f;
+  return MERGE_MARGIN * r * r;
+}
 }  // namespace
 
 void Peng::merge_iupac_patterns(const size_t pattern_length, const float threshold_factor, BackgroundModel*,
@@ -226,13 +234,15 @@ void Peng::merge_iupac_patterns(const size_t pattern_length, const float thresho
     float floor = -std::numeric_limits<float>::infinity();  // device scores below it cannot be the maximum
     if (grid) {
       float amax = -std::numeric_limits<float>::infinity();
+      size_t longest = 0;
       for (size_t i = 0; i < pats.size(); ++i) {
         if (pats[i]->getLogPval() > -5) continue;
+        longest = std::max(longest, (size_t)pats[i]->get_pattern_length());
         const float* row = &approx[serial[i] * S];
         for (size_t j = i + 1; j < pats.size(); ++j)
           if (!(pats[j]->getLogPval() > -5) && row[serial[j]] > amax) amax = row[serial[j]];
       }
-      floor = amax - MERGE_MARGIN;
+      floor = amax - merge_margin(longest);
     }
     for (size_t i = 0; i < pats.size(); ++i) {
       if (pats[i]->getLogPval() > -5) continue;

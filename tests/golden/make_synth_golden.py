@@ -30,6 +30,11 @@ CASES = [  # seed, seq0, n_seq, L, W, strand
     # ... and one WHOLE shard of it (shard 3 of 8: sequences [37.5M, 50M)): 2.65e9 positions, just inside the
     # reference's 32-bit position counters; about 30 GB of host memory and ten minutes
     (1, 37_500_000, 12_500_000, 200, 12, "BOTH"),
+    # BASELINE configs[2] at FULL size (the bench's own workload: 10M x 200 bp, W = 10, both strands) and the PLUS table
+    # configs[4] runs its EM stress on: 2.0e9 bases, inside the reference's `int` base counts, so V, the sweep and the
+    # seed list are pinned as well; about 25 GB of host memory and six minutes each
+    (1, 0, 10_000_000, 200, 10, "BOTH"),
+    (1, 0, 10_000_000, 200, 10, "PLUS"),
 ]
 
 

@@ -43,6 +43,16 @@ def test_single_rank_json_contract():
     assert d["roofline_em"]["flop_per_eval"] == 24 and d["roofline_em"]["frac"] > 0
     e2e = d["components"]["e2e_cli"]
     assert "error" not in e2e and e2e["wall_s"] > 0 and e2e["motifs"] >= 1 and "total" in e2e["phases_s"]
+    # the compiled reference on the same file, same box, same run: the denominator of the end-to-end ratio -- and its
+    # MEME output is this repository's byte for byte
+    same = e2e["reference_same_box"]
+    assert "skipped" not in same, same
+    assert same["reference_wall_s_same_box"] > 0 and same["speedup_same_box"] > 0 and same["meme_identical_to_reference"] is True
+    assert cb["reference_full_size"] == same
+    # labels: only BASELINE.json's own sizes carry its config names; traffic only from a profile of this configuration
+    assert "not a BASELINE.json configuration" in d["config"]["workload"]
+    assert rf["traffic"] is None and "roofline_issue" not in d
+    assert d["roofline_em"]["parity_mode"]["frac"] > 0 and d["roofline_em"]["parity_mode"]["ms"] > 0
 
 
 def test_two_rank_rehearsal_allreduces_the_tables():

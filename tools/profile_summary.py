@@ -3,7 +3,8 @@
   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1`
   <tag>_pmc.txt            mean counter values per kernel of the separate --pmc passes
   <tag>_bench.json         the default bench line of the same build
-  traffic_latest.json      HBM bytes per launch of K1 + the issue counters of its pass A, stamped with the commit
+  traffic_by_config.json   HBM bytes per launch of K1 + the issue counters of its scan, one entry per configuration
+                           (W / size / strand mode), each stamped with the commit it was taken at
 usage: tools/profile_summary.py gpurun_out/<tag> [commit]"""
 import csv
 import glob
@@ -66,40 +67,73 @@ def kernel_ms(prefix):
 
 
 KIB = 1024.0
-sc_f, sc_w = mean("pengk::count_scatter_kernel", "FETCH_SIZE"), mean("pengk::count_scatter_kernel", "WRITE_SIZE")
-hi_f, hi_w = mean("pengk::count_hist_kernel", "FETCH_SIZE"), mean("pengk::count_hist_kernel", "WRITE_SIZE")
-ga_f, ga_w = mean("pengk::count_gather_kernel", "FETCH_SIZE"), mean("pengk::count_gather_kernel", "WRITE_SIZE")
-if None not in (sc_f, sc_w, hi_f, hi_w, ga_f, ga_w):
+# ---- HBM traffic of K1 per launch, for the configuration this profile was taken at --------------------------------------
+# K1 = every pengk::count_* kernel of a pengk_count_bg launch plus bg_finish_fused_kernel.  FETCH_SIZE / WRITE_SIZE are
+# KiB; per MI355X_MICROARCH.md (HBM section) gfx950 reports HALF the bytes of a 16-B-per-lane streaming read, so the
+# kernels that read their keys that way (count_hist_kernel, count_rescatter12_kernel) have FETCH_SIZE doubled; the
+# scans read 4 / 8 B per lane (uncalibrated width): raw value kept.
+bench = None
+if os.path.exists(os.path.join(out, "bench.json")):
+    try:
+        bench = json.loads([l for l in open(os.path.join(out, "bench.json")) if l.startswith("{")][-1])
+    except Exception:
+        bench = None
+WIDE_READERS = ("pengk::count_hist_kernel", "pengk::count_rescatter12_kernel")
+k1 = {}
+total = 0.0
+complete = True
+for name in sorted(agg):
+    if not (name.startswith("pengk::count_") or name.startswith("pengk::bg_finish_fused")):
+        continue
+    f, w = agg[name].get("FETCH_SIZE"), agg[name].get("WRITE_SIZE")
+    if not f or not w:
+        complete = False
+        continue
+    f, w = sum(f) / len(f), sum(w) / len(w)
+    fc = 2 * f if name.startswith(WIDE_READERS) else f
+    k1[name] = {"fetch_bytes_raw": f * KIB, "fetch_bytes_corrected": fc * KIB, "write_bytes": w * KIB}
+    total += (fc + w) * KIB
+if k1 and complete and bench:
+    cfg = bench["config"]
+    W, nseq, L, strand = cfg["W"], cfg["n_seq_per_gpu"], cfg["seq_len"], cfg["strand"]
+    key = "W%d_n%d_L%d_%s" % (W, nseq, L, strand)
     t = {
-        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile_round.sh), bench.py at its default size "
-                "(10M x 200 bp, W=10, both strands), per launch. Counters are KiB. FETCH_SIZE of the 16-B-per-lane streaming read in "
-                "count_hist_kernel is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2); count_scatter_kernel reads 4 B per "
-                "lane (uncalibrated width): raw value kept, doubled value in *_if_doubled.",
-        "commit": commit, "config": "BASELINE configs[2], 10M x 200 bp, W=10, BOTH", "profile": tag,
-        "count_scatter_kernel": {"fetch_bytes_raw": sc_f * KIB, "fetch_bytes_if_doubled": 2 * sc_f * KIB, "write_bytes": sc_w * KIB},
-        "count_hist_kernel": {"fetch_bytes_raw": hi_f * KIB, "fetch_bytes_corrected": 2 * hi_f * KIB, "write_bytes": hi_w * KIB},
-        "count_gather_kernel": {"fetch_bytes_raw": ga_f * KIB, "write_bytes": ga_w * KIB},
-        "count_kernel_hbm_bytes_per_launch": (sc_f + sc_w + 2 * hi_f + hi_w + ga_f + ga_w) * KIB,
-        "algorithmic_bytes_per_launch": 584194304,
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile_round.sh), per pengk_count_bg launch; "
+                "FETCH_SIZE doubled for the 16-B-per-lane streaming readers per MI355X_MICROARCH.md (gfx950 reports 1/2)",
+        "commit": commit, "config": cfg["workload"].split(";")[0], "profile": tag, "kernels": k1,
+        "count_kernel_hbm_bytes_per_launch": total,
+        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
     }
-    valu, salu, lds = (mean("pengk::count_scatter_kernel", c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"))
-    busy, act_valu = mean("pengk::count_scatter_kernel", "SQ_BUSY_CYCLES"), mean("pengk::count_scatter_kernel", "SQ_ACTIVE_INST_VALU")
-    ms = kernel_ms("count_scatter_kernel")
-    if None not in (valu, salu, lds, busy, act_valu, ms):
-        n_simd, clk = 1024, 2.4e9
-        peak = n_simd * clk / 4.0  # one wave-instruction per SIMD every 4 cycles (tools/ubench/valu_rate2.hip: 4.2-4.6 measured)
-        cycles = busy / 32.0       # SQ_BUSY_CYCLES is summed over the 32 shader engines
-        t["issue"] = {
-            "kernel": "count_scatter_kernel<10,both> (pass A of K1)", "bound": "instruction issue (VALU)",
-            "achieved": valu / (ms * 1e-3), "peak": peak, "unit": "VALU wave-instructions/s", "frac": valu / (ms * 1e-3) / peak,
-            "valu_busy_frac": act_valu * 4.0 / (n_simd * cycles),
-            "per_launch": {"valu_wave_instructions": valu, "salu_instructions": salu, "lds_instructions": lds,
-                           "kernel_ms": ms, "busy_cycles_per_shader_engine": cycles,
-                           "wave_steps_of_64_windows": 1.91e9 / 64, "valu_per_wave_step": valu / (1.91e9 / 64),
-                           "all_instructions_per_wave_step": (valu + salu + lds) / (1.91e9 / 64)},
-            "source": "rocprofv3 --pmc SQ_* passes at commit %s (%s), not this run" % (commit, tag),
-            "note": "the byte roofline cannot describe this kernel: it moves 14x its algorithmic bytes and still uses a fifth of the HBM "
-                    "rate; what it is near is the rate at which 4 waves per SIMD (LDS-limited occupancy) can issue instructions",
-        }
-    json.dump(t, open(os.path.join(prof, "traffic_latest.json"), "w"), indent=1)
+    scan = next((n for n in agg if n.startswith("pengk::count_scatter_kernel") or n.startswith("pengk::count_scatter12_kernel")), None)
+    if scan:
+        valu, salu, lds = (mean(scan, c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"))
+        busy, act_valu = mean(scan, "SQ_BUSY_CYCLES"), mean(scan, "SQ_ACTIVE_INST_VALU")
+        ms = kernel_ms(scan.split("::")[1].split("<")[0])
+        if None not in (valu, salu, lds, busy, act_valu, ms):
+            n_simd, clk = 1024, 2.4e9
+            peak4 = n_simd * clk / 4.0  # measured class rate of this kernel's instructions (tools/ubench/valu_rate2.hip)
+            peak2 = n_simd * clk / 2.0  # the guide's nominal SIMD rate (MI355X_MICROARCH.md: 2 cycles per wave64 instruction)
+            cycles = busy / 32.0        # SQ_BUSY_CYCLES is summed over the 32 shader engines
+            steps = cfg["ltot_global"] / 64.0
+            t["issue"] = {
+                "kernel": scan.replace("pengk::", "") + " (the scan of K1)", "bound": "instruction issue (VALU)",
+                "achieved": valu / (ms * 1e-3), "peak": peak4, "unit": "VALU wave-instructions/s", "frac": valu / (ms * 1e-3) / peak4,
+                "peak_nominal_2_cycle": peak2, "frac_of_nominal_2_cycle_rate": valu / (ms * 1e-3) / peak2,
+                "valu_busy_frac": act_valu * 4.0 / (n_simd * cycles),
+                "per_launch": {"valu_wave_instructions": valu, "salu_instructions": salu, "lds_instructions": lds,
+                               "kernel_ms": ms, "busy_cycles_per_shader_engine": cycles,
+                               "wave_steps_of_64_windows": steps, "valu_per_wave_step": valu / steps,
+                               "all_instructions_per_wave_step": (valu + salu + lds) / steps},
+                "source": "rocprofv3 --pmc SQ_* passes at commit %s (%s), not this run" % (commit, tag),
+                "note": "`peak` prices a wave-instruction at 4 cycles per SIMD -- the rate tools/ubench/valu_rate2 MEASURES on this chip for "
+                        "the classes this kernel is made of (v_bfe / v_min / v_cmpx / v_mad_u32_u24, every VOP3 / SDWA / DPP form: 4.2-4.6 "
+                        "cycles); the guide's nominal SIMD rate is 2 cycles (MI355X_MICROARCH.md), `frac_of_nominal_2_cycle_rate` is against "
+                        "that.  The byte roofline cannot describe this kernel: it moves many times its algorithmic bytes and still uses "
+                        "a fraction of the HBM rate",
+            }
+    path = os.path.join(prof, "traffic_by_config.json")
+    allc = json.load(open(path)) if os.path.exists(path) else {}
+    allc[key] = t
+    json.dump(allc, open(path, "w"), indent=1)
+    print("traffic entry", key, "%.3f GB per launch" % (total / 1e9))
 print("\n".join(lines[:60]))
