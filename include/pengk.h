@@ -124,7 +124,20 @@ typedef struct pengk_packed {
  * grants them): release them with pengk_packed_free, never with free(). */
 int pengk_pack(const uint8_t* h_codes, const int64_t* h_offs, int64_t n_seq, int W, int item_windows,
                pengk_packed* out);
+/* The same with a given number of host threads (0 = automatic, as pengk_pack): a caller that packs many chunks of an
+ * input from its own worker threads -- the CLI does, while the FASTA file is still being read -- asks for 1. */
+int pengk_pack_threads(const uint8_t* h_codes, const int64_t* h_offs, int64_t n_seq, int W, int item_windows, int threads,
+                       pengk_packed* out);
 void pengk_packed_free(pengk_packed* p);
+
+/* Streams one packed chunk into caller-owned device buffers that collect the chunks of one input: the chunk's words
+ * land at d_words + word_offset, its items at d_items + item_offset with their stream offsets rebased by
+ * 32 * word_offset bases (every chunk keeps its own zero padding, so the concatenation has the layout above and is
+ * attached with ONE pengk_set_sequences: n_words / n_items = the sums over the chunks, max_bin_bound = the sum,
+ * all_whole = the AND).  Synchronises with the host: on return the chunk's host buffers may be freed.  Counts are
+ * additive over sequences, so the order of the chunks in the buffers does not matter. */
+int pengk_append_packed(pengk_ctx* ctx, uint64_t* d_words, uint64_t word_offset, uint64_t* d_items, uint64_t item_offset,
+                        const pengk_packed* chunk);
 
 /* ---- device-resident sequences ------------------------------------------------------------- */
 /* Attach caller-owned device buffers holding a packed stream and its items (layout above).

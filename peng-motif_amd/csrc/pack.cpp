@@ -370,6 +370,11 @@ int pack_fast(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, i
 
 extern "C" int pengk_pack(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, int item_windows,
                           pengk_packed* out) {
+  return pengk_pack_threads(codes, offs, n_seq, W, item_windows, 0, out);
+}
+
+extern "C" int pengk_pack_threads(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, int item_windows,
+                                  int threads, pengk_packed* out) {
   if (!out) return fail(PENGK_ERR_ARG, "pengk_pack: out is NULL");
   memset(out, 0, sizeof *out);
   if (n_seq < 0 || (n_seq > 0 && (!codes || !offs))) return fail(PENGK_ERR_ARG, "pengk_pack: NULL input");
@@ -385,7 +390,10 @@ extern "C" int pengk_pack(const uint8_t* codes, const int64_t* offs, int64_t n_s
   if (hw == 0) hw = 1;
   if (hw > 32) hw = 32;
   unsigned nt = total < (1u << 22) ? 1u : hw;
-  if (const char* e = getenv("PENGK_PACK_THREADS")) {  // tests: force a thread count
+  if (threads < 0 || threads > 64) return fail(PENGK_ERR_ARG, "pengk_pack_threads: %d threads (0 = automatic, 1..64)", threads);
+  if (threads > 0) {
+    nt = (unsigned)threads;
+  } else if (const char* e = getenv("PENGK_PACK_THREADS")) {  // tests: force a thread count
     const int v = atoi(e);
     if (v >= 1 && v <= 64) nt = (unsigned)v;
   }

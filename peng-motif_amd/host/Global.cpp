@@ -46,7 +46,10 @@ void Global::init(int nargs, char* args[]) {
   pengk_host::start_context();  // the device runtime starts while the FASTA files are read
   pengk_host::start_sharded_ingest();  // multi-GPU run: every rank reads its own byte range of the files
   // both strands are handled inside the count; sequences are always read single stranded
+  // ... and every chunk of the input set is packed and sent to the device while the rest is still being read
+  pengk_host::begin_streaming_pack(patternLength);
   inputSequenceSet = new SequenceSet(inputSequenceFilename, true);
+  pengk_host::finish_streaming_pack(inputSequenceSet);
   // Without --background-sequences the reference reads the input file a second time (src/Global.cpp:66-75) and so
   // prints that file's warnings twice; the set is shared here, its warnings are replayed.
   if (backgroundSequenceFilename) {

@@ -34,18 +34,29 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
   pengk_host::Lap lap("    ");
   // multi-GPU run: the sequence set of this rank holds its shard of whole records only (sharded ingest,
   // shared/SequenceSet.h); the tables are summed below
-  pengk_packed pk;
-  check(pengk_pack(sequence_set->codes(), sequence_set->offsets(), (int64_t)sequence_set->getLocalN(), W, 0, &pk), "pengk_pack");
-  lap("pack");
-  pengk_host::DeviceBuffer<uint64_t> d_words(pk.n_words), d_items(pk.n_items + 1), d_ltot(1);
-  d_words.upload(pk.words, pk.n_words);
-  if (pk.n_items) d_items.upload(pk.items, pk.n_items);
-  check(pengk_set_sequences(context(), d_words.get(), pk.n_words, d_items.get(), pk.n_items, W, pk.item_windows,
-                            pk.max_bin_bound, pk.all_whole),
-        "pengk_set_sequences");
-  check(pengk_set_option(context(), "n_windows_hint", (int64_t)pk.n_windows), "pengk_set_option");
-  pengk_packed_free(&pk);
-  lap("upload");
+  pengk_host::DeviceBuffer<uint64_t> d_words, d_items, d_ltot(1);
+  if (const pengk_host::PackedInput* in = pengk_host::packed_input(sequence_set, W)) {
+    // the CLI's input set: packed and uploaded chunk by chunk while the FASTA file was read (host/device.cpp)
+    check(pengk_set_sequences(context(), in->d_words, in->n_words, in->d_items, in->n_items, W, in->item_windows, in->max_bin_bound,
+                              in->all_whole),
+          "pengk_set_sequences");
+    check(pengk_set_option(context(), "n_windows_hint", (int64_t)in->n_windows), "pengk_set_option");
+    lap("attach (packed and uploaded during the read)");
+  } else {
+    pengk_packed pk;
+    check(pengk_pack(sequence_set->codes(), sequence_set->offsets(), (int64_t)sequence_set->getLocalN(), W, 0, &pk), "pengk_pack");
+    lap("pack");
+    d_words.resize(pk.n_words);
+    d_items.resize(pk.n_items + 1);
+    d_words.upload(pk.words, pk.n_words);
+    if (pk.n_items) d_items.upload(pk.items, pk.n_items);
+    check(pengk_set_sequences(context(), d_words.get(), pk.n_words, d_items.get(), pk.n_items, W, pk.item_windows,
+                              pk.max_bin_bound, pk.all_whole),
+          "pengk_set_sequences");
+    check(pengk_set_option(context(), "n_windows_hint", (int64_t)pk.n_windows), "pengk_set_option");
+    pengk_packed_free(&pk);
+    lap("upload");
+  }
 
   // ---- K1 count (+ twin copy), K2+K3 sweep ---------------------------------------------------------------
   d_counts.resize(NP);

@@ -3,7 +3,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
+#include <deque>
+#include <mutex>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -117,7 +120,138 @@ pengk_ctx* context() {
   return g_ctx;
 }
 
+// ---- streaming pack ------------------------------------------------------------------------------------------------
+namespace {
+struct Stream {
+  PackedInput in;
+  SequenceSet* set = nullptr;
+  size_t words_cap = 0, items_cap = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<pengk_packed> ready;  // packed chunks waiting for the uploader
+  bool done = false;
+  std::string error;               // first packer / upload failure
+  std::thread uploader;
+  bool started = false;
+};
+Stream* g_stream = nullptr;
+
+void stream_fail(Stream* st, const std::string& what) {
+  std::lock_guard<std::mutex> lock(st->mu);
+  if (st->error.empty()) st->error = what;
+}
+
+void sink_begin(void* user, size_t range_bytes, size_t n_chunks) {
+  Stream* st = (Stream*)user;
+  // upper bounds from the bytes of text: a base takes a byte; an item needs a run of >= W bases plus a byte that ends
+  // it, and covers up to item_windows windows
+  const size_t W = (size_t)st->in.W, M = (size_t)PENGK_DEFAULT_ITEM_WINDOWS;
+  st->words_cap = range_bytes / 32 + n_chunks * 8 + 16;
+  st->items_cap = range_bytes / (W + 1) + range_bytes / M + n_chunks + 16;
+  st->started = true;
+  st->uploader = std::thread([st] {
+    uint64_t word_at = 0, item_at = 0;
+    for (;;) {
+      pengk_packed pk;
+      {
+        std::unique_lock<std::mutex> lock(st->mu);
+        st->cv.wait(lock, [st] { return !st->ready.empty() || st->done; });
+        if (st->ready.empty()) return;
+        pk = st->ready.front();
+        st->ready.pop_front();
+      }
+      bool ok;
+      {
+        std::lock_guard<std::mutex> lock(st->mu);
+        ok = st->error.empty();
+      }
+      if (ok && !st->in.d_words) {  // first chunk: the context (started beside the reader) is needed from here on
+        void *w = nullptr, *it = nullptr;
+        ok = pengk_malloc(context(), st->words_cap * sizeof(uint64_t), &w) == PENGK_OK &&
+             pengk_malloc(context(), st->items_cap * sizeof(uint64_t), &it) == PENGK_OK;
+        st->in.d_words = (uint64_t*)w;
+        st->in.d_items = (uint64_t*)it;
+      }
+      if (ok && (word_at + pk.n_words > st->words_cap || item_at + pk.n_items > st->items_cap)) {
+        stream_fail(st, "packed chunks exceed the bounds computed from the file size");
+        ok = false;
+      }
+      if (ok && pengk_append_packed(context(), st->in.d_words, word_at, st->in.d_items, item_at, &pk) != PENGK_OK) ok = false;
+      if (!ok) stream_fail(st, std::string("upload of a packed chunk failed: ") + pengk_last_error());
+      word_at += pk.n_words;
+      item_at += pk.n_items;
+      st->in.n_words = word_at;
+      st->in.n_items = item_at;
+      pengk_packed_free(&pk);
+    }
+  });
+}
+
+void sink_chunk(void* user, size_t, const SequenceChunk& c) {
+  Stream* st = (Stream*)user;
+  if (c.n == 0) return;
+  pengk_packed pk;
+  if (pengk_pack_threads(c.codes, c.offs.data(), (int64_t)c.n, st->in.W, 0, 1, &pk) != PENGK_OK) {
+    stream_fail(st, std::string("pengk_pack failed: ") + pengk_last_error());
+    return;
+  }
+  {
+    std::lock_guard<std::mutex> lock(st->mu);
+    st->in.item_windows = pk.item_windows;
+    st->in.n_windows += pk.n_windows;
+    st->in.max_bin_bound += pk.max_bin_bound;
+    st->in.all_whole &= pk.all_whole;
+    for (int i = 0; i < 84; ++i) st->in.bg_counts[i] += pk.bg_counts[i];
+    st->ready.push_back(pk);
+  }
+  st->cv.notify_one();
+}
+}  // namespace
+
+void begin_streaming_pack(int W) {
+  if (const char* e = std::getenv("PENGK_NO_STREAMING")) {  // the staged path: read, then pack, then upload (tests compare the two)
+    if (std::atoi(e)) return;
+  }
+  delete g_stream;
+  g_stream = new Stream();
+  g_stream->in.W = W;
+  SequenceChunkSink sink;
+  sink.user = g_stream;
+  sink.begin = sink_begin;
+  sink.chunk = sink_chunk;
+  SequenceSet::setChunkSink(sink);
+}
+
+const PackedInput* finish_streaming_pack(SequenceSet* set) {
+  Stream* st = g_stream;
+  if (!st || !st->started) return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(st->mu);
+    st->done = true;
+  }
+  st->cv.notify_all();
+  st->uploader.join();
+  if (!st->error.empty()) {
+    std::cerr << "Error: " << st->error << std::endl;
+    exit(1);
+  }
+  st->set = set;
+  if (!st->in.d_words) return nullptr;  // no records at all on this rank: the staged path handles the empty shard
+  return &st->in;
+}
+
+const PackedInput* packed_input(SequenceSet* set, int W) {
+  Stream* st = g_stream;
+  return st && st->set == set && st->in.W == W && st->in.d_words ? &st->in : nullptr;
+}
+
 void shutdown() {
+  if (g_stream && g_ctx) {
+    if (g_stream->in.d_words) pengk_free(g_ctx, g_stream->in.d_words);
+    if (g_stream->in.d_items) pengk_free(g_ctx, g_stream->in.d_items);
+  }
+  delete g_stream;
+  g_stream = nullptr;
   if (g_ctx) pengk_destroy(g_ctx);
   g_ctx = nullptr;
 }

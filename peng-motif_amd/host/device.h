@@ -12,6 +12,8 @@
 
 #include "pengk.h"
 
+class SequenceSet;
+
 namespace pengk_host {
 
 pengk_ctx* context();           // created on first use on Global::device
@@ -30,6 +32,24 @@ bool launched();  // WORLD_SIZE is set (even to 1): the run goes through the com
 void start_sharded_ingest();
 // launched runs: waits for every rank, then releases the communicator and the host channel (call before leaving)
 void finish_ranks();
+
+// The input set of the run, packed while it is read: the FASTA reader hands every finished chunk of records to the
+// packer on its own worker threads (SequenceChunkSink, shared/SequenceSet.h), an uploader thread sends the packed chunks
+// to the device as they arrive (pengk_append_packed) -- the device context is still starting when the first ones are
+// ready -- so that packing and upload hide behind the read (src/main.cpp:18-84 does these steps one after the other).
+// The packer's background counters come with it: when the input set doubles as the background set (the default,
+// src/Global.cpp:66-75) the model is built from them and no separate pass over the sequences is needed.
+struct PackedInput {
+  int W = 0, item_windows = 0;
+  uint64_t* d_words = nullptr;  // device buffers that collected the chunks (owned here, released with the context)
+  uint64_t* d_items = nullptr;
+  uint64_t n_words = 0, n_items = 0, n_windows = 0, max_bin_bound = 0;
+  int all_whole = 1;
+  long long bg_counts[84] = {0};  // this rank's records (BaMM ids), as BackgroundModel counts them
+};
+void begin_streaming_pack(int W);                              // the NEXT SequenceSet constructed is packed as it is read
+const PackedInput* finish_streaming_pack(::SequenceSet* set);    // waits for the last upload; nullptr if nothing was packed
+const PackedInput* packed_input(::SequenceSet* set, int W);      // of a set that went through the two calls above, else nullptr
 
 // PENGK_TIMING=1: wall-clock report of sub-phases on stderr (stdout stays the reference's trace)
 struct Lap {

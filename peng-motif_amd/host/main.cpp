@@ -47,14 +47,21 @@ int main(int nargs, char** args) {
   // shard and follows the same deterministic control flow on the all-reduced tables; rank 0 alone reports and writes
   if (pengk_host::rank() != 0 && !std::freopen("/dev/null", "w", stdout)) return 1;
   Global::init(nargs, args);
-  clock.lap("read FASTA");
+  clock.lap("read FASTA (+ pack + upload, chunk by chunk)");
   // (the device context is being created on a helper thread since Global::init; nothing waits for it before the packed
   // sequences are ready for upload -- BasePattern's first device call -- and a machine without a gfx950 device fails
   // there, loudly: there is no CPU path)
 
   const int bg_model_order = std::max(Global::bgModelOrder, Global::maxOptBgModelOrder);
+  // the input set doubles as the background set unless --background-sequences names another file: its (k+1)-mer
+  // counters were taken by the packer while the file was read
+  const pengk_host::PackedInput* packed = Global::backgroundSequenceSet == Global::inputSequenceSet
+                                              ? pengk_host::packed_input(Global::inputSequenceSet, Global::patternLength)
+                                              : nullptr;
   BackgroundModel* bgModel =
-      new BackgroundModel(*Global::backgroundSequenceSet, bg_model_order, Global::bgModelAlpha, Global::interpolateBG);
+      packed ? new BackgroundModel(*Global::backgroundSequenceSet, bg_model_order, Global::bgModelAlpha, Global::interpolateBG,
+                                   packed->bg_counts)
+             : new BackgroundModel(*Global::backgroundSequenceSet, bg_model_order, Global::bgModelAlpha, Global::interpolateBG);
 
   clock.lap("background model");
   Peng peng(Global::strand, Global::bgModelOrder, Global::maxOptBgModelOrder, Global::inputSequenceSet, bgModel);

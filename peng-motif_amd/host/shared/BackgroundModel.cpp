@@ -3,13 +3,13 @@
 // is counted; otherwise every (k+1)-mer ending at i >= k is.  calculateV follows :490-530 in float32.
 #include "BackgroundModel.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <thread>
 
-BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vector<float> alpha, bool interpolate,
-                                 std::vector<std::vector<int>>, std::vector<int>) {
+void BackgroundModel::init(SequenceSet& sequenceSet, int order, std::vector<float> alpha, bool interpolate) {
   if (order < 0 || order > 2 || (int)alpha.size() < order + 1) {
     std::cerr << "Error: background model order " << order << " is not supported (0..2)" << std::endl;
     exit(-1);
@@ -26,18 +26,37 @@ BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vecto
     n_[k] = new long long[1 << (2 * (k + 1))]();
     v_[k] = new float[1 << (2 * (k + 1))]();
   }
-  // count over the contiguous code buffer, split over host threads by sequence ranges
-  const uint8_t* codes = sequenceSet.codes();
-  const int64_t* offs = sequenceSet.offsets();
-  const size_t N = sequenceSet.getLocalN();  // this rank's records; the counters are summed over the ranks below
+}
+
+BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vector<float> alpha, bool interpolate,
+                                 const long long* counts84) {
+  init(sequenceSet, order, alpha, interpolate);
+  for (int k = 0, at = 0; k < 3; at += 1 << (2 * (k + 1)), ++k)
+    for (int y = 0; y < (1 << (2 * (k + 1))); ++y) n_[k][y] = counts84[at + y];
+  for (int k = 0; k < 3; ++k) SequenceSet::allreduceSum(n_[k], (size_t)1 << (2 * (k + 1)));
+  calculateV();
+}
+
+BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vector<float> alpha, bool interpolate,
+                                 std::vector<std::vector<int>>, std::vector<int>) {
+  init(sequenceSet, order, alpha, interpolate);
+  // count over this rank's chunks of records (the counters are summed over the ranks below), chunks dealt to host threads
+  const size_t NC = sequenceSet.nChunks();
   unsigned nt = std::thread::hardware_concurrency();
   if (nt == 0) nt = 1;
   if (nt > 32) nt = 32;
-  if (N == 0 || (size_t)offs[N] < (1u << 22)) nt = 1;
+  if (NC < nt) nt = NC ? (unsigned)NC : 1u;
   std::vector<std::vector<long long>> part(nt, std::vector<long long>(168, 0));  // [0,84) fast path, [84,168) exact path
+  std::atomic<size_t> next{0};
   auto work = [&](unsigned t) {
     long long* c[3] = {part[t].data(), part[t].data() + 4, part[t].data() + 20};
-    for (size_t s = N * t / nt; s < N * (t + 1) / nt; ++s) {
+    for (;;) {
+      const size_t ci = next.fetch_add(1);
+      if (ci >= NC) return;
+      const SequenceChunk& ch = sequenceSet.chunk(ci);
+      const uint8_t* codes = ch.codes;
+      const int64_t* offs = ch.offs.data();
+    for (size_t s = 0; s < ch.n; ++s) {
       const uint8_t* seq = codes + offs[s];
       const int64_t L = offs[s + 1] - offs[s];
       if (!std::memchr(seq, 0, (size_t)L)) {
@@ -71,6 +90,7 @@ BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vecto
           if (invalid == 0 || y == 0) ++d[k][y];
         }
       }
+    }
     }
   };
   {

@@ -13,6 +13,10 @@ class BackgroundModel {
   BackgroundModel(SequenceSet& sequenceSet, int order, std::vector<float> alpha, bool interpolate = true,
                   std::vector<std::vector<int>> foldIndices = std::vector<std::vector<int>>(),
                   std::vector<int> folds = std::vector<int>());
+  // The same model from (k+1)-mer counters somebody else has taken over this rank's records of `sequenceSet` -- the
+  // packer counts them on its way (pengk_packed.bg_counts, exactly the counters of src/shared/BackgroundModel.cpp:60-84):
+  // 84 values, orders 0..2 back to back, BaMM ids.  Summed over the ranks like the counting constructor's.
+  BackgroundModel(SequenceSet& sequenceSet, int order, std::vector<float> alpha, bool interpolate, const long long* counts84);
   ~BackgroundModel();
 
   std::string getName() { return name_; }
@@ -21,6 +25,7 @@ class BackgroundModel {
   const long long* getCounts(int k) const { return n_[k]; }  // (k+1)-mer counts, BaMM (big-endian) ids
 
  private:
+  void init(SequenceSet& sequenceSet, int order, std::vector<float> alpha, bool interpolate);
   void calculateV();
   std::string name_;
   int K_;

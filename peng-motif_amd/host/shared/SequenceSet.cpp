@@ -5,6 +5,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,56 +28,16 @@ void* sequence_set_huge_alloc(std::size_t bytes) {
   return p;
 }
 
-SequenceSet::SequenceSet(std::string sequenceFilepath, bool single_stranded, std::string intensityFilepath) {
-  if (Alphabet::getSize() == 0) {
-    std::cerr << "Error: Initialize Alphabet before constructing a SequenceSet" << std::endl;
-    exit(-1);
-  }
-  path_ = sequenceFilepath;
-  single_stranded_ = single_stranded;
-  minL_ = std::numeric_limits<int>::max();
-  maxL_ = 0;
-  for (float& f : base_freq_) f = 0.f;
-  offs_.assign(1, 0);
-  readFASTA();
-  if (!intensityFilepath.empty()) {
-    std::cerr << "Error: SequenceSet::readIntensities() is not implemented so far." << std::endl;
-    exit(1);
-  }
-}
-
-SequenceSet::~SequenceSet() {
-  for (Sequence* s : sequences_) delete s;
-  std::free(codes_);
-}
-
-std::vector<Sequence*> SequenceSet::getSequences() {
-  if (!materialised_) {
-    const size_t n = getLocalN();
-    sequences_.reserve(n);
-    for (size_t i = 0; i < n; ++i) {
-      const int L = (int)(offs_[i + 1] - offs_[i]);
-      if (single_stranded_) {
-        sequences_.push_back(Sequence::view(codes_ + offs_[i], L, header(i)));
-      } else {
-        sequences_.push_back(new Sequence(codes_ + offs_[i], L, header(i), std::vector<int>(), false));
-      }
-    }
-    materialised_ = true;
-  }
-  return sequences_;
-}
-
 namespace {
-
-struct Span {
-  size_t begin, end;  // record text [begin, end): header line first
-};
 
 unsigned host_threads(size_t bytes) {
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 1;
   if (hw > 32) hw = 32;
+  if (const char* e = std::getenv("PENGK_READ_THREADS")) {  // tests: force a thread count
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 64) return (unsigned)v;
+  }
   return bytes < (1u << 22) ? 1u : hw;
 }
 
@@ -92,22 +54,30 @@ void parallel_for(unsigned nt, F&& f) {
   f(0u);
 }
 
+bool pread_all(int fd, char* dst, size_t n, size_t at) {
+  while (n) {
+    const ssize_t k = pread(fd, dst, n, (off_t)at);
+    if (k <= 0) return false;
+    dst += k;
+    at += (size_t)k;
+    n -= (size_t)k;
+  }
+  return true;
+}
+
 // first record start ('>' at the start of a line) at or after `from`, or `limit` when there is none
 size_t next_record_start(int fd, size_t from, size_t limit, bool* io_error) {
   if (from == 0) return 0;
   if (from >= limit) return limit;
-  std::vector<char> buf((size_t)1 << 20);
+  std::vector<char> buf;
   size_t pos = from - 1;  // buf[0] is the byte in front of the first candidate
+  size_t step = (size_t)16 << 10;
   while (pos + 1 < limit) {
-    const size_t want = std::min(buf.size(), limit - pos);
-    size_t got = 0;
-    while (got < want) {
-      const ssize_t k = pread(fd, buf.data() + got, want - got, (off_t)(pos + got));
-      if (k <= 0) {
-        *io_error = true;
-        return limit;
-      }
-      got += (size_t)k;
+    buf.resize(step);
+    const size_t got = std::min(buf.size(), limit - pos);
+    if (!pread_all(fd, buf.data(), got, pos)) {
+      *io_error = true;
+      return limit;
     }
     const char* p = buf.data() + 1;
     const char* e = buf.data() + got;
@@ -116,6 +86,7 @@ size_t next_record_start(int fd, size_t from, size_t limit, bool* io_error) {
       ++p;
     }
     pos += got - 1;
+    step = (size_t)1 << 20;
   }
   return limit;
 }
@@ -130,12 +101,166 @@ struct ShardSummary {
 };
 enum { FASTA_OK = 0, FASTA_OPEN = 1, FASTA_FORMAT = 2, FASTA_SPACE = 3, FASTA_NOMEM = 4 };
 
+// what a worker reports about one chunk
+struct ChunkStat {
+  int error = FASTA_OK;
+  size_t records = 0, empty = 0;
+  int64_t bases = 0;
+  uint32_t maxL = 0, minL = std::numeric_limits<uint32_t>::max();
+  unsigned long counts[4] = {0, 0, 0, 0};
+  std::string last_warnings;  // last chunk of the file only
+};
+
 SequenceShardComm g_shard_comm;
+SequenceChunkSink g_sink;
+
+constexpr size_t CHUNK_BYTES = (size_t)8 << 20;
+
+// One chunk, start to end, on the calling thread: text [s, e) of the file (starts on a header unless s == 0, ends in
+// front of a header or at the end of the range) -> kept records as byte codes.
+// Parsing quirks of the reference (src/shared/SequenceSet.cpp:285-447): blank lines are skipped, a header without
+// sequence is dropped, a space inside a sequence line or text in front of the first header is an error.
+void read_chunk(int fd, size_t s, size_t e, bool file_end, const uint8_t* lut, bool standard, std::vector<char>& text,
+                std::vector<size_t>& hdr, std::vector<uint32_t>& len, SequenceChunk& out, ChunkStat& st) {
+  const size_t size = e - s;
+  if (text.size() < size) text.resize(size + size / 8);
+  if (size && !pread_all(fd, text.data(), size, s)) {
+    st.error = FASTA_OPEN;
+    return;
+  }
+  const char* t = text.data();
+  // ---- headers: '>' at the start of a line ----------------------------------------------------------------
+  hdr.clear();
+  for (const char* p = t; p < t + size;) {
+    p = (const char*)memchr(p, '>', (size_t)(t + size - p));
+    if (!p) break;
+    const size_t at = (size_t)(p - t);
+    if (at == 0 || t[at - 1] == '\n') hdr.push_back(at);
+    ++p;
+  }
+  // anything but blank lines in front of the first header is a format error (reference: exit(1)); only the chunk at
+  // the head of the file can hold such text -- every other chunk starts on a header
+  {
+    const size_t first = hdr.empty() ? size : hdr[0];
+    for (size_t i = 0; i < first; ++i)
+      if (t[i] != '\n') {
+        st.error = FASTA_FORMAT;
+        return;
+      }
+  }
+  const size_t R = hdr.size();
+  hdr.push_back(size);
+  st.records = R;
+  // ---- measure every record (sequence length, spaces) --------------------------------------------------------
+  len.resize(R);
+  size_t K = 0;
+  uint64_t hbytes = 0;
+  for (size_t r = 0; r < R; ++r) {
+    const char* p = t + hdr[r];
+    const char* end = t + hdr[r + 1];
+    const char* h_end = (const char*)memchr(p, '\n', (size_t)(end - p));  // the header line (terminated: ranges end on '\n')
+    const size_t hl = (size_t)(h_end - p - 1);
+    p = h_end + 1;
+    size_t n = 0;
+    while (p < end) {
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+      const size_t l = (size_t)(nl - p);
+      if (l && memchr(p, ' ', l)) {
+        st.error = FASTA_SPACE;
+        return;
+      }
+      n += l;
+      p = nl + 1;
+    }
+    len[r] = (uint32_t)n;
+    if (n == 0) {
+      ++st.empty;
+      continue;
+    }
+    ++K;
+    st.bases += (int64_t)n;
+    hbytes += hl;
+    if (n > st.maxL) st.maxL = (uint32_t)n;
+    if (n < st.minL) st.minL = (uint32_t)n;
+  }
+  // ---- translate ------------------------------------------------------------------------------------------------
+  // A C G T (either case) -> 1 2 3 4, every other byte -> 0 (Alphabet.cpp:33-41), written as branch-free byte
+  // arithmetic so that the compiler vectorises the line loop; base counts per line the same way.
+  out.n = K;
+  out.offs.resize(K + 1);
+  out.hdr_off.resize(K + 1);
+  out.hdr_pool.resize((size_t)hbytes);
+  out.codes = (uint8_t*)sequence_set_huge_alloc((size_t)st.bases);
+  if (!out.codes) {
+    st.error = FASTA_NOMEM;
+    return;
+  }
+  out.offs[0] = 0;
+  out.hdr_off[0] = 0;
+  size_t k = 0;
+  for (size_t r = 0; r < R; ++r) {
+    if (len[r] == 0) continue;
+    const char* p = t + hdr[r];
+    const char* end = t + hdr[r + 1];
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+    // (">" alone: an empty header, read back as the 1-based index among the kept records -- reference: N+1)
+    const size_t hl = (size_t)(nl - p - 1);
+    if (hl) memcpy(out.hdr_pool.data() + out.hdr_off[k], p + 1, hl);
+    out.hdr_off[k + 1] = out.hdr_off[k] + hl;
+    out.offs[k + 1] = out.offs[k] + len[r];
+    uint8_t* dst = out.codes + out.offs[k];
+    ++k;
+    p = nl + 1;
+    while (p < end) {
+      nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+      const size_t l = (size_t)(nl - p);
+      const uint8_t* in = (const uint8_t*)p;
+      if (standard) {
+        unsigned a = 0, c2 = 0, g = 0, tt = 0;
+        for (size_t i = 0; i < l; ++i) {
+          const uint8_t u = (uint8_t)(in[i] & 0xDF);  // upper case
+          const uint8_t ia = u == 'A', ic = u == 'C', ig = u == 'G', it = u == 'T';
+          dst[i] = (uint8_t)(ia + 2 * ic + 3 * ig + 4 * it);
+          a += ia;
+          c2 += ic;
+          g += ig;
+          tt += it;
+        }
+        st.counts[0] += a;
+        st.counts[1] += c2;
+        st.counts[2] += g;
+        st.counts[3] += tt;
+      } else {
+        for (size_t i = 0; i < l; ++i) {
+          const uint8_t c = lut[in[i]];
+          dst[i] = c;
+          if (c) ++st.counts[c - 1];
+        }
+      }
+      dst += l;
+      p = nl + 1;
+    }
+  }
+  // The reference reports undefined bases only for the LAST record of the file -- the one its reader handles behind
+  // the line loop (src/shared/SequenceSet.cpp:395-405); records closed by a following header are translated silently
+  // (:328-336).  Same stderr here: the chunk that holds the end of the file collects the offending characters.
+  if (file_end && R && len[R - 1] != 0) {
+    const char* p = t + hdr[R - 1];
+    const char* end = t + hdr[R];
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+    std::string bad_chars;
+    for (const char* q = nl + 1; q < end; ++q)
+      if (*q != '\n' && lut[(uint8_t)*q] == 0) bad_chars += *q;
+    // carried to rank 0 as: header text (empty for '>' alone), a line feed, the offending characters
+    if (!bad_chars.empty()) st.last_warnings = std::string(p + 1, (size_t)(nl - p - 1)) + "\n" + bad_chars;
+  }
+}
 
 }  // namespace
 
 void SequenceSet::setShardComm(const SequenceShardComm& comm) { g_shard_comm = comm; }
 const SequenceShardComm& SequenceSet::shardComm() { return g_shard_comm; }
+void SequenceSet::setChunkSink(const SequenceChunkSink& sink) { g_sink = sink; }
 
 void SequenceSet::allreduceSum(long long* values, size_t n) {
   const SequenceShardComm& sc = g_shard_comm;
@@ -152,283 +277,194 @@ void SequenceSet::allreduceSum(long long* values, size_t n) {
   }
 }
 
-void SequenceSet::readFASTA() {
+SequenceSet::SequenceSet(std::string sequenceFilepath, bool single_stranded, std::string intensityFilepath) {
+  if (Alphabet::getSize() == 0) {
+    std::cerr << "Error: Initialize Alphabet before constructing a SequenceSet" << std::endl;
+    exit(-1);
+  }
+  path_ = sequenceFilepath;
+  single_stranded_ = single_stranded;
+  minL_ = std::numeric_limits<int>::max();
+  maxL_ = 0;
+  for (float& f : base_freq_) f = 0.f;
+  const SequenceChunkSink sink = g_sink;  // for this set only
+  g_sink = SequenceChunkSink();
+  readFASTA(sink);
+  if (!intensityFilepath.empty()) {
+    std::cerr << "Error: SequenceSet::readIntensities() is not implemented so far." << std::endl;
+    exit(1);
+  }
+}
+
+SequenceSet::~SequenceSet() {
+  for (Sequence* s : sequences_) delete s;
+  for (SequenceChunk& c : chunks_) std::free(c.codes);
+  std::free(flat_codes_);
+}
+
+std::string SequenceSet::header(size_t k) const {
+  // the chunk that holds local record k
+  size_t lo = 0, hi = chunks_.size();
+  while (hi - lo > 1) {
+    const size_t mid = (lo + hi) / 2;
+    if (chunks_[mid].first <= k) lo = mid;
+    else hi = mid;
+  }
+  const SequenceChunk& c = chunks_[lo];
+  const size_t j = k - c.first;
+  const uint64_t b = c.hdr_off[j], e = c.hdr_off[j + 1];
+  return e == b ? std::to_string(k_base_ + k + 1) : std::string(c.hdr_pool.data() + b, (size_t)(e - b));
+}
+
+std::vector<Sequence*> SequenceSet::getSequences() {
+  if (!materialised_) {
+    sequences_.reserve(n_local_);
+    for (const SequenceChunk& c : chunks_)
+      for (size_t j = 0; j < c.n; ++j) {
+        const int L = (int)(c.offs[j + 1] - c.offs[j]);
+        if (single_stranded_) {
+          sequences_.push_back(Sequence::view(c.codes + c.offs[j], L, header(c.first + j)));
+        } else {
+          sequences_.push_back(new Sequence(c.codes + c.offs[j], L, header(c.first + j), std::vector<int>(), false));
+        }
+      }
+    materialised_ = true;
+  }
+  return sequences_;
+}
+
+void SequenceSet::flatten() {
+  if (flat_codes_ || flat_offs_.size()) return;
+  int64_t total = 0;
+  for (const SequenceChunk& c : chunks_) total += c.n ? c.offs[c.n] : 0;
+  flat_codes_ = (uint8_t*)sequence_set_huge_alloc((size_t)total);
+  flat_offs_.resize(n_local_ + 1);
+  if (!flat_codes_) {
+    std::cerr << "Error: out of memory reading " << path_ << std::endl;
+    exit(1);
+  }
+  int64_t at = 0;
+  size_t k = 0;
+  flat_offs_[0] = 0;
+  for (const SequenceChunk& c : chunks_) {
+    if (!c.n) continue;
+    memcpy(flat_codes_ + at, c.codes, (size_t)c.offs[c.n]);
+    for (size_t j = 0; j < c.n; ++j) flat_offs_[++k] = at + c.offs[j + 1];
+    at += c.offs[c.n];
+  }
+}
+
+void SequenceSet::readFASTA(const SequenceChunkSink& sink) {
   const SequenceShardComm& sc = g_shard_comm;
   ShardSummary mine{};
   std::string last_record_warnings;
-  raw_vector<uint32_t> len;  // sequence length of every record of the shard (0: dropped)
-  size_t R = 0;              // records of the shard
-  bool owns_file_end = false;
 
   // ---- this rank's part of the file: everything a single process does with the whole file ---------------------------
   auto local_pass = [&]() -> int {
-  const int fd = open(path_.c_str(), O_RDONLY);
-  struct stat sb;
-  if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
-    if (fd >= 0) close(fd);
-    return FASTA_OPEN;
-  }
-  size_t file_size = (size_t)sb.st_size;
-  // the reference's getline(...).good() loop never yields a final line without '\n'
-  {
-    char tail[4096];
-    while (file_size) {
-      const size_t n = std::min(sizeof tail, file_size);
-      if (pread(fd, tail, n, (off_t)(file_size - n)) != (ssize_t)n) {
-        close(fd);
-        return FASTA_OPEN;
+    const int fd = open(path_.c_str(), O_RDONLY);
+    struct FdGuard {
+      int fd;
+      ~FdGuard() {
+        if (fd >= 0) close(fd);
       }
-      size_t i = n;
-      while (i && tail[i - 1] != '\n') --i;
-      file_size -= n - i;
-      if (i) break;
+    } fd_guard{fd};
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return FASTA_OPEN;
+    size_t file_size = (size_t)sb.st_size;
+    // the reference's getline(...).good() loop never yields a final line without '\n'
+    {
+      char tail[4096];
+      while (file_size) {
+        const size_t n = std::min(sizeof tail, file_size);
+        if (!pread_all(fd, tail, n, file_size - n)) return FASTA_OPEN;
+        size_t i = n;
+        while (i && tail[i - 1] != '\n') --i;
+        file_size -= n - i;
+        if (i) break;
+      }
     }
-  }
-  // byte range of this rank, cut at record starts
-  size_t lo = 0, hi = file_size;
-  if (sc.world > 1) {
+    // byte range of this rank, cut at record starts
+    size_t lo = 0, hi = file_size;
     bool io_error = false;
-    lo = next_record_start(fd, (size_t)((unsigned __int128)file_size * sc.rank / sc.world), file_size, &io_error);
-    if (sc.rank + 1 < sc.world)
-      hi = next_record_start(fd, (size_t)((unsigned __int128)file_size * (sc.rank + 1) / sc.world), file_size, &io_error);
-    if (io_error) {
-      close(fd);
-      return FASTA_OPEN;
+    if (sc.world > 1) {
+      lo = next_record_start(fd, (size_t)((unsigned __int128)file_size * sc.rank / sc.world), file_size, &io_error);
+      if (sc.rank + 1 < sc.world)
+        hi = next_record_start(fd, (size_t)((unsigned __int128)file_size * (sc.rank + 1) / sc.world), file_size, &io_error);
+      if (io_error) return FASTA_OPEN;
     }
-  }
-  owns_file_end = hi == file_size && hi > lo;
-  const size_t size = hi - lo;
-  // The range is copied into an anonymous buffer on huge pages by all threads (pread) instead of mapped: mapping touches
-  // every 4 KiB page of the page cache once per process, and that first touch was most of the reader's time for a
-  // 2 GB input (the three passes below then also run on 2 MiB pages).
-  char* text = nullptr;
-  struct TextGuard {
-    char*& p;
-    ~TextGuard() { std::free(p); }
-  } text_guard{text};
-  if (size) {
-    text = (char*)sequence_set_huge_alloc(size);
-    if (!text) {
-      close(fd);
-      return FASTA_NOMEM;
+    const bool owns_file_end = hi == file_size && hi > lo;
+    const size_t range = hi - lo;
+
+    // chunks of the range; every worker finds the record starts that bound ITS chunk (two short reads), reads the chunk
+    // into its own buffer -- a few MiB that stay in cache, instead of a file-sized buffer whose pages are touched once
+    // by the copy and once by each pass -- and carries it through all stages
+    const unsigned nt_all = host_threads(range);
+    size_t C = nt_all == 1 ? 1 : std::max<size_t>(1, range / CHUNK_BYTES);
+    if (const char* e = std::getenv("PENGK_READ_CHUNKS")) {  // tests: force a chunk count
+      const long v = std::atol(e);
+      if (v >= 1 && v <= 65536) C = (size_t)v;
     }
-    const unsigned nr = host_threads(size);
-    std::vector<int> failed(nr, 0);
-    parallel_for(nr, [&](unsigned t) {
-      size_t at = size * t / nr;
-      const size_t end = size * (t + 1) / nr;
-      while (at < end) {
-        const ssize_t got = pread(fd, text + at, end - at, (off_t)(lo + at));
-        if (got <= 0) {
-          failed[t] = 1;
-          return;
+    if (C > range) C = range ? range : 1;
+    const unsigned nt = (unsigned)std::min<size_t>(nt_all, C);
+    chunks_.assign(C, SequenceChunk());
+    std::vector<ChunkStat> stat(C);
+
+    uint8_t lut[256];
+    bool standard = true;  // does the arithmetic of read_chunk reproduce the alphabet's table for every byte?
+    for (int c = 0; c < 256; ++c) {
+      lut[c] = Alphabet::getCode((char)c);
+      const int u = c & 0xDF;
+      standard &= lut[c] == (u == 'A') + 2 * (u == 'C') + 3 * (u == 'G') + 4 * (u == 'T');
+    }
+    if (sink.begin) sink.begin(sink.user, range, C);
+    std::atomic<size_t> next{0};
+    parallel_for(nt, [&](unsigned) {
+      std::vector<char> text;
+      std::vector<size_t> hdr;
+      std::vector<uint32_t> len;
+      for (;;) {
+        const size_t c = next.fetch_add(1);
+        if (c >= C) return;
+        bool io = false;
+        const size_t a = lo + (size_t)((unsigned __int128)range * c / C), b = lo + (size_t)((unsigned __int128)range * (c + 1) / C);
+        const size_t s = c == 0 ? lo : std::max(lo, next_record_start(fd, a, hi, &io));
+        const size_t e = c + 1 == C ? hi : std::max(lo, next_record_start(fd, b, hi, &io));
+        if (io) {
+          stat[c].error = FASTA_OPEN;
+        } else {
+          // (the chunk that reaches the end of the file holds its last record: a record longer than a chunk leaves the
+          // chunks behind it empty)
+          read_chunk(fd, s, e, owns_file_end && e == hi && s < e, lut, standard, text, hdr, len, chunks_[c], stat[c]);
         }
-        at += (size_t)got;
+        // (a chunk with an error ends the run after the read: every chunk is still looked at, so that the error
+        // reported is the first one in file order)
+        if (!stat[c].error && sink.chunk) sink.chunk(sink.user, c, chunks_[c]);
       }
     });
-    for (int f : failed)
-      if (f) {
-        close(fd);
-        return FASTA_OPEN;
+    // the first error in file order is the one a single reader would have met
+    for (size_t c = 0; c < C; ++c)
+      if (stat[c].error) return stat[c].error;
+    mine.minL = minL_;
+    for (size_t c = 0; c < C; ++c) {
+      chunks_[c].first = (size_t)mine.kept;
+      mine.records += stat[c].records;
+      mine.kept += chunks_[c].n;
+      mine.empty += stat[c].empty;
+      mine.bases += (uint64_t)stat[c].bases;
+      if (chunks_[c].n) {
+        mine.maxL = std::max<uint64_t>(mine.maxL, stat[c].maxL);
+        mine.minL = std::min<uint64_t>(mine.minL, stat[c].minL);
       }
-  }
-  close(fd);
-
-  const unsigned nt = host_threads(size);
-
-  // ---- 1. headers: '>' at the start of a line ---------------------------------------------------------
-  std::vector<std::vector<size_t>> found(nt);
-  parallel_for(nt, [&](unsigned t) {
-    const size_t lo = size * t / nt, hi = size * (t + 1) / nt;
-    const char* p = text + lo;
-    while (p < text + hi) {
-      p = (const char*)memchr(p, '>', (size_t)(text + hi - p));
-      if (!p) break;
-      const size_t at = (size_t)(p - text);
-      if (at == 0 || text[at - 1] == '\n') found[t].push_back(at);
-      ++p;
+      for (int i = 0; i < 4; ++i) mine.counts[i] += stat[c].counts[i];
     }
-  });
-  std::vector<size_t> hdr;
-  for (auto& v : found) hdr.insert(hdr.end(), v.begin(), v.end());
-  // anything but blank lines in front of the first header is a format error (reference: exit(1))
-  // (only the rank that holds the head of the file can see such text: every other range starts on a header)
-  {
-    const size_t first = hdr.empty() ? size : hdr[0];
-    for (size_t i = 0; i < first; ++i)
-      if (text[i] != '\n') return FASTA_FORMAT;
-  }
-  R = hdr.size();
-  hdr.push_back(size);
-
-  // ---- 2. measure every record (sequence length, spaces) ---------------------------------------------------
-  raw_vector<uint32_t> hlen(R);
-  len.resize(R);  // both written for every record below
-  std::vector<int> bad(nt, 0);
-  auto record_cut = [&](unsigned t) { return (size_t)((uint64_t)R * t / nt); };
-  parallel_for(nt, [&](unsigned t) {
-    for (size_t r = record_cut(t); r < record_cut(t + 1); ++r) {
-      const char* p = text + hdr[r];
-      const char* end = text + hdr[r + 1];
-      const char* h_end = (const char*)memchr(p, '\n', (size_t)(end - p));  // the header line (terminated: size ends on '\n')
-      hlen[r] = (uint32_t)(h_end - p - 1);
-      p = h_end + 1;
-      size_t n = 0;
-      while (p < end) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const size_t l = (size_t)(nl - p);
-        if (l && memchr(p, ' ', l)) bad[t] = 1;
-        n += l;
-        p = nl + 1;
+    // the undefined bases of the file's last record: with the chunk that holds it (the last one with a record)
+    for (size_t c = C; c-- > 0;)
+      if (stat[c].records) {
+        last_record_warnings = stat[c].last_warnings;
+        break;
       }
-      len[r] = (uint32_t)n;
-    }
-  });
-  for (int b : bad)
-    if (b) return FASTA_SPACE;
-
-  // ---- 3. offsets of the kept records, headers -------------------------------------------------------------
-  // Two parallel passes over the records (totals per thread range, then every range writes its own entries): with
-  // push_backs, one std::string per header and value-initialised arrays this step ran on one thread and was the
-  // longest of the reader at 10M records.
-  struct Part {
-    size_t kept = 0, empty = 0;
-    int64_t bases = 0;
-    uint64_t hbytes = 0;
-    uint32_t maxL = 0, minL = std::numeric_limits<uint32_t>::max();
-  };
-  std::vector<Part> part(nt);
-  parallel_for(nt, [&](unsigned t) {
-    Part p;
-    for (size_t r = record_cut(t); r < record_cut(t + 1); ++r) {
-      const uint32_t l = len[r];
-      if (l == 0) {
-        ++p.empty;
-        continue;
-      }
-      ++p.kept;
-      p.bases += l;
-      p.hbytes += hlen[r];
-      p.maxL = l > p.maxL ? l : p.maxL;
-      p.minL = l < p.minL ? l : p.minL;
-    }
-    part[t] = p;
-  });
-  size_t K = 0, n_empty = 0;
-  int64_t total = 0;
-  uint64_t htotal = 0;
-  std::vector<Part> base(nt);  // what lies in front of each thread's range
-  for (unsigned t = 0; t < nt; ++t) {
-    base[t].kept = K;
-    base[t].bases = total;
-    base[t].hbytes = htotal;
-    K += part[t].kept;
-    n_empty += part[t].empty;
-    total += part[t].bases;
-    htotal += part[t].hbytes;
-    if (part[t].kept) {
-      if (part[t].maxL > maxL_) maxL_ = part[t].maxL;
-      if (part[t].minL < minL_) minL_ = part[t].minL;
-    }
-  }
-  mine.records = R;
-  mine.kept = K;
-  mine.empty = n_empty;
-  mine.bases = (uint64_t)total;
-  mine.minL = minL_;
-  mine.maxL = maxL_;
-  raw_vector<size_t> kept(K);
-  offs_.resize(K + 1);
-  hdr_off_.resize(K + 1);
-  offs_[0] = 0;
-  hdr_off_[0] = 0;
-  parallel_for(nt, [&](unsigned t) {
-    size_t k = base[t].kept;
-    int64_t at = base[t].bases;
-    uint64_t hat = base[t].hbytes;
-    for (size_t r = record_cut(t); r < record_cut(t + 1); ++r) {
-      if (len[r] == 0) continue;
-      kept[k] = r;
-      at += len[r];
-      hat += hlen[r];
-      ++k;
-      offs_[k] = at;
-      hdr_off_[k] = hat;
-    }
-  });
-  hdr_pool_.resize((size_t)htotal);
-  codes_ = (uint8_t*)sequence_set_huge_alloc((size_t)total);
-  if (!codes_) return FASTA_NOMEM;
-
-  // ---- 4. translate ------------------------------------------------------------------------------------------------
-  // A C G T (either case) -> 1 2 3 4, every other byte -> 0 (Alphabet.cpp:33-41), written as branch-free byte
-  // arithmetic so that the compiler vectorises the line loop; base counts per line the same way.
-  uint8_t lut[256];
-  bool standard = true;  // does the arithmetic below reproduce the alphabet's table for every byte?
-  for (int c = 0; c < 256; ++c) {
-    lut[c] = Alphabet::getCode((char)c);
-    const int u = c & 0xDF;
-    standard &= lut[c] == (u == 'A') + 2 * (u == 'C') + 3 * (u == 'G') + 4 * (u == 'T');
-  }
-  std::vector<std::vector<unsigned long>> counts(nt, std::vector<unsigned long>(5, 0));
-  parallel_for(nt, [&](unsigned t) {
-    unsigned long* bc = counts[t].data();
-    for (size_t k = (size_t)((uint64_t)K * t / nt); k < (size_t)((uint64_t)K * (t + 1) / nt); ++k) {
-      const size_t r = kept[k];
-      const char* p = text + hdr[r];
-      const char* end = text + hdr[r + 1];
-      const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-      // (">" alone: an empty header, read back as the 1-based index among the kept records -- reference: N+1)
-      if (nl - p > 1) memcpy(hdr_pool_.data() + hdr_off_[k], p + 1, (size_t)(nl - p - 1));
-      p = nl + 1;
-      uint8_t* out = codes_ + offs_[k];
-      while (p < end) {
-        nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const size_t l = (size_t)(nl - p);
-        const uint8_t* in = (const uint8_t*)p;
-        if (standard) {
-          unsigned a = 0, c2 = 0, g = 0, tt = 0;
-          for (size_t i = 0; i < l; ++i) {
-            const uint8_t u = (uint8_t)(in[i] & 0xDF);  // upper case
-            const uint8_t ia = u == 'A', ic = u == 'C', ig = u == 'G', it = u == 'T';
-            out[i] = (uint8_t)(ia + 2 * ic + 3 * ig + 4 * it);
-            a += ia;
-            c2 += ic;
-            g += ig;
-            tt += it;
-          }
-          bc[1] += a;
-          bc[2] += c2;
-          bc[3] += g;
-          bc[4] += tt;
-        } else {
-          for (size_t i = 0; i < l; ++i) {
-            const uint8_t c = lut[in[i]];
-            out[i] = c;
-            ++bc[c];
-          }
-        }
-        out += l;
-        p = nl + 1;
-      }
-    }
-  });
-  // The reference reports undefined bases only for the LAST record of the file -- the one its reader handles behind
-  // the line loop (src/shared/SequenceSet.cpp:395-405); records closed by a following header are translated silently
-  // (:328-336).  Same stderr here: the rank that holds the end of the file collects the offending characters.
-  if (owns_file_end && R && len[R - 1] != 0) {
-    const char* p = text + hdr[R - 1];
-    const char* end = text + hdr[R];
-    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-    std::string bad_chars;
-    for (const char* q = nl + 1; q < end; ++q)
-      if (*q != '\n' && lut[(uint8_t)*q] == 0) bad_chars += *q;
-    // carried to rank 0 as: header text (empty for '>' alone), a line feed, the offending characters
-    if (!bad_chars.empty()) last_record_warnings = std::string(p + 1, (size_t)(nl - p - 1)) + "\n" + bad_chars;
-  }
-  for (auto& c : counts)
-    for (int i = 0; i < 4; ++i) mine.counts[i] += c[i + 1];
-  return FASTA_OK;
+    n_local_ = (size_t)mine.kept;
+    return FASTA_OK;
   };  // local_pass
 
   mine.error = (uint64_t)local_pass();
@@ -471,6 +507,7 @@ void SequenceSet::readFASTA() {
   }
   // warnings: rank 0 speaks for the file, in file order (identical lines: the reference prints one per empty record as
   // it meets it; the last record's undefined bases come last)
+  if (owner >= 0 && owner != sc.rank) last_record_warnings.clear();  // (an earlier rank's last record is not the file's)
   if (sc.world > 1 && owner >= 0 && all[(size_t)owner].warn_bytes) {
     const size_t n = (size_t)all[(size_t)owner].warn_bytes;
     std::vector<char> send(n, 0), recv(n * (size_t)sc.world);

@@ -4,9 +4,8 @@
 // a space inside a sequence line or a sequence before any header ends the program with exit(1).
 //
 // Ingest is built for 10^7-record inputs (83 % of the reference's wall time at BASELINE config 3,
-// SURVEY.md 8f.1): the file is mmap'ed, headers are located and records translated by all host cores,
-// and the codes of all records live in ONE contiguous buffer (codes() / offsets()) that the packer
-// consumes without a copy.  Sequence objects are only materialised if getSequences() is called.
+// SURVEY.md 8f.1): the file is read in chunks by all host cores (below); Sequence objects are only
+// materialised if getSequences() is called.
 #ifndef PENGK_HOST_SEQUENCESET_H_
 #define PENGK_HOST_SEQUENCESET_H_
 
@@ -67,6 +66,26 @@ struct SequenceShardComm {
   bool (*allgather)(const void* send, void* recv, size_t bytes) = nullptr;
 };
 
+// The reader works in CHUNKS: byte ranges of a few MiB, cut at record starts, each read (pread into a buffer that stays
+// in cache), parsed and translated by one host thread from start to end -- so the first chunks are complete while the
+// rest of the file is still being read, and a consumer can take them from there: the CLI packs every chunk to 2 bits per
+// base and sends it to the GPU as it arrives (host/device.cpp), which hides packing and upload behind the read.
+struct SequenceChunk {
+  uint8_t* codes = nullptr;        // byte codes of the chunk's kept records, back to back
+  raw_vector<int64_t> offs;        // n + 1 offsets into codes (offs[0] = 0)
+  raw_vector<char> hdr_pool;       // headers, compact: header k = hdr_pool[hdr_off[k] .. hdr_off[k + 1])
+  raw_vector<uint64_t> hdr_off;
+  size_t n = 0;                    // kept records
+  size_t first = 0;                // index of the chunk's first record among this rank's records (set after the read)
+};
+struct SequenceChunkSink {
+  void* user = nullptr;
+  // before the first chunk: `range_bytes` of FASTA text will arrive in `n_chunks` chunks (an upper bound on the bases)
+  void (*begin)(void* user, size_t range_bytes, size_t n_chunks) = nullptr;
+  // from the reader's worker threads, concurrently, in any order: chunk `index` is complete
+  void (*chunk)(void* user, size_t index, const SequenceChunk& c) = nullptr;
+};
+
 class SequenceSet {
  public:
   SequenceSet(std::string sequenceFilepath, bool single_stranded = false, std::string intensityFilepath = "");
@@ -77,6 +96,8 @@ class SequenceSet {
   static const SequenceShardComm& shardComm();
   // sum over the ranks of n 64-bit counters (in place) through shardComm(); exits(1) when a rank is lost
   static void allreduceSum(long long* values, size_t n);
+  // consumer of the chunks of the NEXT set that is constructed (cleared by that constructor)
+  static void setChunkSink(const SequenceChunkSink& sink);
 
   std::string getSequenceFilepath() { return path_; }
   // the warnings this set's constructor wrote to stderr (a caller that re-uses the set where the reference reads the
@@ -84,32 +105,31 @@ class SequenceSet {
   const std::string& diagnostics() const { return diagnostics_; }
   std::vector<Sequence*> getSequences();  // materialises views on first use
   size_t getN() { return n_global_; }                 // records of the whole file (all ranks)
-  size_t getLocalN() { return offs_.size() - 1; }      // records this rank holds: codes() / offsets() / getSequences()
+  size_t getLocalN() { return n_local_; }              // records this rank holds
   size_t getLocalBase() { return k_base_; }            // number of records in front of this rank's first one
   unsigned int getMinL() { return minL_; }
   unsigned int getMaxL() { return maxL_; }
   float* getBaseFrequencies() { return base_freq_; }
 
-  // contiguous representation: codes of local record i are codes()[offsets()[i] .. offsets()[i+1])
-  const uint8_t* codes() const { return codes_; }
-  const int64_t* offsets() const { return offs_.data(); }
+  // this rank's records, chunk by chunk, in file order
+  size_t nChunks() const { return chunks_.size(); }
+  const SequenceChunk& chunk(size_t i) const { return chunks_[i]; }
+  // contiguous copy, made on first use (tools and callers that want one array): codes of local record i are
+  // codes()[offsets()[i] .. offsets()[i+1])
+  const uint8_t* codes() { return flatten(), flat_codes_; }
+  const int64_t* offsets() { return flatten(), flat_offs_.data(); }
 
  private:
-  void readFASTA();
+  void readFASTA(const SequenceChunkSink& sink);
+  void flatten();
+  std::string header(size_t k) const;  // of local record k
   std::string path_;
   std::string diagnostics_;
   bool single_stranded_;
-  uint8_t* codes_ = nullptr;
-  raw_vector<int64_t> offs_;
-  // headers, compact: header k = hdr_pool_[hdr_off_[k] .. hdr_off_[k+1]); an empty one (">" alone in the file) reads as
-  // the record's 1-based index among the kept records, like the reference's N+1
-  raw_vector<char> hdr_pool_;
-  raw_vector<uint64_t> hdr_off_;
-  std::string header(size_t k) const {
-    const uint64_t b = hdr_off_[k], e = hdr_off_[k + 1];
-    return e == b ? std::to_string(k_base_ + k + 1) : std::string(hdr_pool_.data() + b, (size_t)(e - b));
-  }
-  size_t n_global_ = 0, k_base_ = 0;
+  std::vector<SequenceChunk> chunks_;
+  uint8_t* flat_codes_ = nullptr;
+  raw_vector<int64_t> flat_offs_;
+  size_t n_global_ = 0, n_local_ = 0, k_base_ = 0;
   std::vector<Sequence*> sequences_;
   bool materialised_ = false;
   unsigned int minL_, maxL_;

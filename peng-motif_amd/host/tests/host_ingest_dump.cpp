@@ -78,11 +78,18 @@ int main(int argc, char** argv) {
       std::printf(" %08x", u);
     }
   std::printf("\n");
-  // views materialise lazily and agree with the contiguous buffer
+  // views materialise lazily (they point into the reader's chunks) and agree with the contiguous copy
   std::vector<Sequence*> seqs = ss.getSequences();
   bool ok = seqs.size() == N;
   for (size_t i = 0; ok && i < N; i += (N / 50 + 1))
-    ok = seqs[i]->getL() == (int)(ss.offsets()[i + 1] - ss.offsets()[i]) && seqs[i]->getSequence() == ss.codes() + ss.offsets()[i];
+    ok = seqs[i]->getL() == (int)(ss.offsets()[i + 1] - ss.offsets()[i]) &&
+         std::memcmp(seqs[i]->getSequence(), ss.codes() + ss.offsets()[i], (size_t)seqs[i]->getL()) == 0;
+  size_t in_chunks = 0;
+  for (size_t c = 0; c < ss.nChunks(); ++c) {
+    ok = ok && ss.chunk(c).first == in_chunks;
+    in_chunks += ss.chunk(c).n;
+  }
+  ok = ok && in_chunks == N;
   std::printf("views %s\n", ok ? "ok" : "BAD");
   if (N) std::printf("header0 %s\n", seqs[0]->getHeader().c_str());
   if (argc >= 6) {  // this rank's codes and record lengths, for the test to lay end to end

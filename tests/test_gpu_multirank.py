@@ -142,3 +142,23 @@ def test_a_rank_that_never_arrives_is_an_error_not_a_hang(tmp_path):
     r = subprocess.run([CLI, os.path.join(GOLD, "MafK_100seqs.fasta"), "-w", "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=env, timeout=120)
     assert r.returncode == 1 and b"only 1 of 2 ranks" in r.stderr
+
+
+@pytest.mark.parametrize("args", [["torture.fa", "-w", "6"], ["MafK.fasta", "-w", "10"], ["MafK.fasta", "-w", "12", "--strand", "PLUS"]],
+                         ids=["torture_w6", "mafk_w10", "mafk_w12_plus"])
+def test_streaming_pack_equals_the_staged_path(tmp_path, args):
+    """The CLI packs and uploads every chunk of the input while the file is still being read (host/device.cpp) and takes
+    the background counters from the packer; PENGK_NO_STREAMING=1 keeps the staged order read -> background model ->
+    pack -> upload.  Same bytes on stdout / stderr / MEME / JSON, also with the reader forced into many small chunks on
+    several threads (chunks then arrive out of order; torture.fa sends its chunks down the packer's general path)."""
+    args = [os.path.join(GOLD, args[0])] + args[1:]
+    outs = []
+    for tag, extra in (("staged", {"PENGK_NO_STREAMING": "1"}), ("streamed", {}),
+                       ("chunks", {"PENGK_READ_CHUNKS": "23", "PENGK_READ_THREADS": "5"}),
+                       ("chunks_staged", {"PENGK_READ_CHUNKS": "7", "PENGK_READ_THREADS": "3", "PENGK_NO_STREAMING": "1"})):
+        meme, js = tmp_path / (tag + ".meme"), tmp_path / (tag + ".json")
+        r = subprocess.run([CLI] + args + ["-o", str(meme), "-j", str(js)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=clean_env(**extra), timeout=900)
+        assert r.returncode == 0, (tag, r.stderr.decode()[-2000:])
+        outs.append((r.stdout, r.stderr, meme.read_bytes(), js.read_bytes()))
+    assert outs[0] == outs[1] == outs[2] == outs[3]
