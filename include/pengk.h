@@ -130,14 +130,25 @@ int pengk_pack_threads(const uint8_t* h_codes, const int64_t* h_offs, int64_t n_
                        pengk_packed* out);
 void pengk_packed_free(pengk_packed* p);
 
-/* Streams one packed chunk into caller-owned device buffers that collect the chunks of one input: the chunk's words
- * land at d_words + word_offset, its items at d_items + item_offset with their stream offsets rebased by
- * 32 * word_offset bases (every chunk keeps its own zero padding, so the concatenation has the layout above and is
- * attached with ONE pengk_set_sequences: n_words / n_items = the sums over the chunks, max_bin_bound = the sum,
- * all_whole = the AND).  Synchronises with the host: on return the chunk's host buffers may be freed.  Counts are
- * additive over sequences, so the order of the chunks in the buffers does not matter. */
-int pengk_append_packed(pengk_ctx* ctx, uint64_t* d_words, uint64_t word_offset, uint64_t* d_items, uint64_t item_offset,
-                        const pengk_packed* chunk);
+/* Packing an input chunk by chunk into ONE pair of caller-owned host buffers (zero-filled; e.g. fresh anonymous
+ * memory), from any number of threads at once: every call reserves its place with the two cursors (atomically), writes
+ * its words -- own zero padding in front and behind, like pengk_pack -- and its items with ABSOLUTE stream offsets, so
+ * that words[0 .. word_cursor) / items[0 .. item_cursor) are attached to the device as they stand, with ONE
+ * pengk_set_sequences: max_bin_bound = the sum over the chunks, all_whole = the AND.  Counts are additive over
+ * sequences, so the order in which chunks land does not matter.  `out` receives the chunk's figures (windows, bounds,
+ * background counters ...); out->words / out->items point INTO the buffers and are not to be released.
+ * The CLI packs every chunk of the FASTA file this way while the rest is still being read (host/device.cpp).
+ * Capacity: words >= sum over chunks of (64 + bases + 31) / 32 + 4, items >= their number; PENGK_ERR_RANGE otherwise. */
+typedef struct pengk_pack_target {
+  uint64_t* words;
+  uint64_t words_cap;
+  uint64_t* items;
+  uint64_t items_cap;
+  uint64_t word_cursor; /* next free word / item: start at 0; advanced atomically by the calls */
+  uint64_t item_cursor;
+} pengk_pack_target;
+int pengk_pack_append(const uint8_t* h_codes, const int64_t* h_offs, int64_t n_seq, int W, int item_windows,
+                      pengk_pack_target* target, pengk_packed* out);
 
 /* ---- device-resident sequences ------------------------------------------------------------- */
 /* Attach caller-owned device buffers holding a packed stream and its items (layout above).

@@ -24,7 +24,7 @@ EXPORTS = [
     "pengk_version", "pengk_last_error", "pengk_error_name", "pengk_create", "pengk_destroy", "pengk_synchronize",
     "pengk_stream", "pengk_set_stream", "pengk_set_option", "pengk_get_info", "pengk_malloc", "pengk_free", "pengk_memcpy_h2d", "pengk_memcpy_d2h",
     "pengk_memset", "pengk_host_alloc", "pengk_host_free", "pengk_timer_create", "pengk_timer_record", "pengk_timer_elapsed_ms", "pengk_timer_destroy",
-    "pengk_pack", "pengk_pack_threads", "pengk_append_packed", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
+    "pengk_pack", "pengk_pack_threads", "pengk_pack_append", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
     "pengk_count", "pengk_count_bg", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
     "pengk_seed_candidates", "pengk_iupac_aggregate", "pengk_em", "pengk_em_device", "pengk_sequential_sum_f32", "pengk_motif_similarity",
     "pengk_comm_unique_id", "pengk_comm_init", "pengk_comm_init_env", "pengk_comm_info", "pengk_comm_destroy",
@@ -84,7 +84,7 @@ def lib():
         L.pengk_timer_destroy.argtypes = [vp, vp]
         L.pengk_pack.argtypes = [vp, vp, i64, C.c_int, C.c_int, C.POINTER(PackedStruct)]
         L.pengk_pack_threads.argtypes = [vp, vp, i64, C.c_int, C.c_int, C.c_int, C.POINTER(PackedStruct)]
-        L.pengk_append_packed.argtypes = [vp, vp, u64, vp, u64, C.POINTER(PackedStruct)]
+        L.pengk_pack_append.argtypes = [vp, vp, i64, C.c_int, C.c_int, vp, C.POINTER(PackedStruct)]
         L.pengk_packed_free.restype = None
         L.pengk_packed_free.argtypes = [C.POINTER(PackedStruct)]
         L.pengk_set_sequences.argtypes = [vp, vp, u64, vp, u64, C.c_int, C.c_int, u64, C.c_int]

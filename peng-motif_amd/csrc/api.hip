@@ -45,14 +45,6 @@ int enter(pengk_ctx* ctx) {
 
 using namespace pengk;
 
-namespace {
-// items of a chunk that was packed on its own: stream offsets (low 40 bits) moved to the chunk's place in the collection
-__global__ __launch_bounds__(256) void rebase_items_kernel(uint64_t* __restrict__ items, uint64_t n, uint64_t delta_bases) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) items[i] += delta_bases;  // (the sum stays below 2^40: checked by the caller)
-}
-}  // namespace
-
 #define PENGK_ENTER(ctx)               \
   do {                                 \
     int rc_enter_ = ::pengk::enter(ctx); \
@@ -314,24 +306,6 @@ int pengk_set_sequences(pengk_ctx* ctx, const uint64_t* d_words, uint64_t n_word
   ctx->max_bin_bound = max_bin_bound;
   ctx->all_whole = all_whole;
   ctx->n_windows_hint = 0;
-  return PENGK_OK;
-}
-
-int pengk_append_packed(pengk_ctx* ctx, uint64_t* d_words, uint64_t word_offset, uint64_t* d_items, uint64_t item_offset,
-                        const pengk_packed* chunk) {
-  if (!ctx || !d_words || !d_items || !chunk || !chunk->words) return fail(PENGK_ERR_ARG, "pengk_append_packed: NULL argument");
-  PENGK_ENTER(ctx);
-  if ((word_offset + chunk->n_words) * 32 > ITEM_WS_MASK) return fail(PENGK_ERR_RANGE, "packed stream exceeds 2^40 bases; shard the input");
-  PENGK_HIP(hipMemcpyAsync(d_words + word_offset, chunk->words, chunk->n_words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  if (chunk->n_items) {
-    PENGK_HIP(hipMemcpyAsync(d_items + item_offset, chunk->items, chunk->n_items * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    if (word_offset) {
-      hipLaunchKernelGGL(rebase_items_kernel, dim3((unsigned)((chunk->n_items + 255) / 256)), dim3(256), 0, ctx->stream,
-                         d_items + item_offset, chunk->n_items, word_offset * 32);
-      PENGK_HIP(hipGetLastError());
-    }
-  }
-  PENGK_HIP(hipStreamSynchronize(ctx->stream));
   return PENGK_OK;
 }
 

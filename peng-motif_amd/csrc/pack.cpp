@@ -475,6 +475,87 @@ extern "C" int pengk_pack_threads(const uint8_t* codes, const int64_t* offs, int
   return PENGK_OK;
 }
 
+// ---- packing into buffers that collect the chunks of one input (the CLI's streaming ingest) -----------------------
+// One thread per call, any number of calls at once: a chunk reserves its place with two atomic cursors -- words by the
+// upper bound its bases give (exact when every sequence is one whole run), items by their exact number, known before
+// the first item is written on both paths -- and writes absolute stream offsets, so the collection is attached to the
+// device as it stands.  No allocation per chunk: the buffers are the caller's, zero-filled once.
+extern "C" int pengk_pack_append(const uint8_t* codes, const int64_t* offs, int64_t n_seq, int W, int item_windows,
+                                 pengk_pack_target* tg, pengk_packed* out) {
+  if (!out || !tg || !tg->words || !tg->items) return fail(PENGK_ERR_ARG, "pengk_pack_append: NULL argument");
+  memset(out, 0, sizeof *out);
+  if (n_seq < 0 || (n_seq > 0 && (!codes || !offs))) return fail(PENGK_ERR_ARG, "pengk_pack_append: NULL input");
+  if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported (even, %d..%d)", W, PENGK_MIN_W, PENGK_MAX_W);
+  if (item_windows == 0) item_windows = PENGK_DEFAULT_ITEM_WINDOWS;
+  if (item_windows < PENGK_MIN_ITEM_WINDOWS || item_windows > 65535)
+    return fail(PENGK_ERR_ARG, "item_windows %d out of range [%d,65535]", item_windows, PENGK_MIN_ITEM_WINDOWS);
+  const uint64_t M = (uint64_t)item_windows;
+  const uint64_t total = n_seq ? (uint64_t)(offs[n_seq] - offs[0]) : 0;
+  const uint64_t n_words = (PENGK_FRONT_PAD_BASES + total + 31) / 32 + 4;  // >= 96 zero bases behind the data
+  const uint64_t w0 = __atomic_fetch_add(&tg->word_cursor, n_words, __ATOMIC_RELAXED);
+  if (w0 + n_words > tg->words_cap) return fail(PENGK_ERR_RANGE, "pengk_pack_append: the word buffer is full");
+  if ((w0 + n_words) * 32 > ITEM_WS_MASK) return fail(PENGK_ERR_RANGE, "packed stream exceeds 2^40 bases; shard the input");
+  const uint64_t g0 = w0 * 32 + PENGK_FRONT_PAD_BASES;  // stream position of the chunk's first base
+  out->n_words = n_words;
+  out->words = tg->words + w0;  // (borrowed: not to be released)
+  out->n_sequences = (uint64_t)n_seq;
+  out->W = W;
+  out->item_windows = item_windows;
+
+  const char* force_general = getenv("PENGK_PACK_GENERAL");  // tests: compare the two paths
+  if (n_seq > 0 && !(force_general && atoi(force_general))) {
+    FastStat st;
+    fast_range(codes, offs, 0, n_seq, W, M, g0, tg->words, st);
+    if (st.ok) {
+      const uint64_t i0 = __atomic_fetch_add(&tg->item_cursor, st.items, __ATOMIC_RELAXED);
+      if (i0 + st.items > tg->items_cap) return fail(PENGK_ERR_RANGE, "pengk_pack_append: the item buffer is full");
+      uint64_t it = i0;
+      for (int64_t s = 0; s < n_seq; ++s) {
+        const uint64_t run0 = g0 + (uint64_t)(offs[s] - offs[0]);
+        const uint64_t nwin = (uint64_t)(offs[s + 1] - offs[s] - W + 1);
+        for (uint64_t f = 0; f < nwin; f += M) {
+          const uint64_t nw = nwin - f < M ? nwin - f : M;
+          tg->items[it++] = (run0 + f) | (nw << ITEM_NW_SHIFT) | ((uint64_t)(f ? 1 : 0) << ITEM_CONT_SHIFT);
+        }
+      }
+      int64_t* bg0 = out->bg_counts;
+      int64_t* bg1 = out->bg_counts + 4;
+      int64_t* bg2 = out->bg_counts + 20;
+      for (int x = 0; x < 64; ++x) {
+        const int a = x & 3, b = (x >> 2) & 3, c = x >> 4;  // a = first base
+        bg2[a * 16 + b * 4 + c] += (int64_t)st.h3[x];
+        bg1[b * 4 + c] += (int64_t)st.h3[x];
+      }
+      for (int y = 0; y < 16; ++y) bg1[y] += (int64_t)st.e1[y];
+      for (int y = 0; y < 16; ++y) bg0[y & 3] += bg1[y];
+      for (int b = 0; b < 4; ++b) bg0[b] += (int64_t)st.e0[b];
+      out->items = tg->items + i0;
+      out->n_items = st.items;
+      out->n_bases = total;
+      out->n_windows = st.windows;
+      out->max_bin_bound = st.bound;
+      out->max_len = st.max_len;
+      out->all_whole = 1;
+      return PENGK_OK;
+    }
+    memset(tg->words + w0, 0, n_words * sizeof(uint64_t));  // what the abandoned fast pass wrote
+  }
+  RangeStat st;
+  measure_range(codes, offs, 0, n_seq, W, M, st);
+  const uint64_t i0 = __atomic_fetch_add(&tg->item_cursor, st.items, __ATOMIC_RELAXED);
+  if (i0 + st.items > tg->items_cap) return fail(PENGK_ERR_RANGE, "pengk_pack_append: the item buffer is full");
+  write_range(codes, offs, 0, n_seq, W, M, g0, i0, tg->words, tg->items);
+  for (int i = 0; i < 84; ++i) out->bg_counts[i] = st.bg[i];
+  out->items = tg->items + i0;
+  out->n_items = st.items;
+  out->n_bases = st.bases;
+  out->n_windows = st.windows;
+  out->max_bin_bound = st.bound;
+  out->max_len = st.max_len;
+  out->all_whole = st.all_whole;
+  return PENGK_OK;
+}
+
 extern "C" void pengk_packed_free(pengk_packed* p) {
   if (!p) return;
   block_free(p->words);

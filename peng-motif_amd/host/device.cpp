@@ -1,16 +1,17 @@
 #include "device.h"
 
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
-#include <deque>
 #include <mutex>
 #include <cstdlib>
 #include <iostream>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "Global.h"
 #include "shared/SequenceSet.h"
@@ -86,10 +87,12 @@ void start_context() {
   atexit(join_starter);  // an exit() on a FASTA error must not tear the process down under a starting runtime
 }
 
-pengk_ctx* context() {
-  if (g_starter.joinable()) {
-    g_starter.join();  // (a failed start has already ended the process)
-  }
+// the context itself, without the communicator of a multi-rank run: what the uploader thread of the streaming pack
+// may call while the main thread is busy on the host channel
+static std::mutex g_ctx_mu;
+static pengk_ctx* raw_context() {
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  if (g_starter.joinable()) g_starter.join();  // (a failed start has already ended the process)
   if (!g_ctx) check(pengk_create(device_index(), &g_ctx), "pengk_create");
   static bool options_set = false;
   if (!options_set) {
@@ -101,6 +104,15 @@ pengk_ctx* context() {
     int mode = 2;
     if (const char* e = std::getenv("PENGK_EM_FAST")) mode = std::atoi(e);
     check(pengk_set_option(g_ctx, "em_fast", mode), "pengk_set_option");
+  }
+  return g_ctx;
+}
+
+pengk_ctx* context() {
+  pengk_ctx* ctx = raw_context();
+  static bool comm_set = false;  // main thread only: the communicator is built by a collective over the ranks
+  if (!comm_set) {
+    comm_set = true;
     if (launched()) {  // RCCL over xGMI; collective: every rank gets here
       // librccl announces its version on stdout while the communicator is built; stdout is the reference's trace
       // (compared byte for byte), so that line goes to stderr
@@ -108,7 +120,7 @@ pengk_ctx* context() {
       fflush(stdout);
       const int saved = dup(1);
       if (saved >= 0) dup2(2, 1);
-      const int rc = pengk_comm_init_env(g_ctx);
+      const int rc = pengk_comm_init_env(ctx);
       fflush(stdout);
       if (saved >= 0) {
         dup2(saved, 1);
@@ -117,22 +129,30 @@ pengk_ctx* context() {
       check(rc, "pengk_comm_init_env");
     }
   }
-  return g_ctx;
+  return ctx;
 }
 
 // ---- streaming pack ------------------------------------------------------------------------------------------------
 namespace {
+constexpr uint64_t SLAB_WORDS = (uint64_t)4 << 20;  // the uploader sends the stream in pieces of 32 MiB as they fill up
+
 struct Stream {
   PackedInput in;
   SequenceSet* set = nullptr;
-  size_t words_cap = 0, items_cap = 0;
+  pengk_pack_target target{};      // host buffers that collect the chunks (fresh anonymous memory: zero-filled)
+  size_t words_bytes = 0, items_bytes = 0;
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<pengk_packed> ready;  // packed chunks waiting for the uploader
+  std::vector<uint64_t> slab_fill; // words written into every slab so far
+  uint64_t reserved_end = 0;       // highest word any finished chunk reaches
   bool done = false;
   std::string error;               // first packer / upload failure
   std::thread uploader;
   bool started = false;
+  ~Stream() {
+    if (target.words) munmap(target.words, words_bytes);
+    if (target.items) munmap(target.items, items_bytes);
+  }
 };
 Stream* g_stream = nullptr;
 
@@ -141,60 +161,94 @@ void stream_fail(Stream* st, const std::string& what) {
   if (st->error.empty()) st->error = what;
 }
 
+void* map_zero(size_t bytes) {
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (p == MAP_FAILED) return nullptr;
+  if (!std::getenv("PENGK_NO_HUGEPAGES")) madvise(p, bytes, MADV_HUGEPAGE);
+  return p;
+}
+
+// slabs [from, ...) that are full -- or, once the reader is done, everything up to the end -- go to the device
+void upload_loop(Stream* st) {
+  uint64_t sent = 0;  // words [0, sent) are on the device
+  for (;;) {
+    uint64_t upto = sent;
+    bool last = false;
+    {
+      std::unique_lock<std::mutex> lock(st->mu);
+      for (;;) {
+        upto = sent;
+        while (upto / SLAB_WORDS < st->slab_fill.size() && st->slab_fill[upto / SLAB_WORDS] == SLAB_WORDS) upto += SLAB_WORDS;
+        if (upto > sent || st->done) break;
+        st->cv.wait(lock);
+      }
+      if (upto == sent) {  // done, and no further full slab: the rest in one piece
+        upto = st->reserved_end;
+        last = true;
+      }
+      if (!st->error.empty()) return;
+    }
+    if (upto > sent) {
+      if (!st->in.d_words) {  // first piece: the context (started beside the reader) is needed from here on
+        void* w = nullptr;
+        if (pengk_malloc(raw_context(), st->target.words_cap * sizeof(uint64_t), &w) != PENGK_OK) {
+          stream_fail(st, std::string("device buffer for the packed stream: ") + pengk_last_error());
+          return;
+        }
+        st->in.d_words = (uint64_t*)w;
+      }
+      if (pengk_memcpy_h2d(raw_context(), st->in.d_words + sent, st->target.words + sent, (upto - sent) * sizeof(uint64_t)) != PENGK_OK) {
+        stream_fail(st, std::string("upload of the packed stream failed: ") + pengk_last_error());
+        return;
+      }
+      sent = upto;
+    }
+    if (last) break;
+  }
+  // the items: one piece, at the end (a sixth of the stream's bytes)
+  const uint64_t n_items = __atomic_load_n(&st->target.item_cursor, __ATOMIC_RELAXED);
+  if (st->in.d_words) {
+    void* it = nullptr;
+    if (pengk_malloc(raw_context(), (n_items + 1) * sizeof(uint64_t), &it) != PENGK_OK ||
+        (n_items && pengk_memcpy_h2d(raw_context(), it, st->target.items, n_items * sizeof(uint64_t)) != PENGK_OK)) {
+      stream_fail(st, std::string("upload of the scan items failed: ") + pengk_last_error());
+      return;
+    }
+    st->in.d_items = (uint64_t*)it;
+  }
+  st->in.n_words = sent;
+  st->in.n_items = n_items;
+}
+
 void sink_begin(void* user, size_t range_bytes, size_t n_chunks) {
   Stream* st = (Stream*)user;
   // upper bounds from the bytes of text: a base takes a byte; an item needs a run of >= W bases plus a byte that ends
-  // it, and covers up to item_windows windows
+  // it, and covers up to item_windows windows.  Address space only: pages are touched as chunks land on them.
   const size_t W = (size_t)st->in.W, M = (size_t)PENGK_DEFAULT_ITEM_WINDOWS;
-  st->words_cap = range_bytes / 32 + n_chunks * 8 + 16;
-  st->items_cap = range_bytes / (W + 1) + range_bytes / M + n_chunks + 16;
+  st->target.words_cap = range_bytes / 32 + n_chunks * 8 + 16;
+  st->target.items_cap = range_bytes / (W + 1) + range_bytes / M + n_chunks + 16;
+  st->words_bytes = st->target.words_cap * sizeof(uint64_t);
+  st->items_bytes = st->target.items_cap * sizeof(uint64_t);
+  st->target.words = (uint64_t*)map_zero(st->words_bytes);
+  st->target.items = (uint64_t*)map_zero(st->items_bytes);
+  if (!st->target.words || !st->target.items) {
+    stream_fail(st, "out of memory for the packed stream");
+    return;
+  }
+  st->slab_fill.assign((size_t)(st->target.words_cap / SLAB_WORDS + 1), 0);
   st->started = true;
-  st->uploader = std::thread([st] {
-    uint64_t word_at = 0, item_at = 0;
-    for (;;) {
-      pengk_packed pk;
-      {
-        std::unique_lock<std::mutex> lock(st->mu);
-        st->cv.wait(lock, [st] { return !st->ready.empty() || st->done; });
-        if (st->ready.empty()) return;
-        pk = st->ready.front();
-        st->ready.pop_front();
-      }
-      bool ok;
-      {
-        std::lock_guard<std::mutex> lock(st->mu);
-        ok = st->error.empty();
-      }
-      if (ok && !st->in.d_words) {  // first chunk: the context (started beside the reader) is needed from here on
-        void *w = nullptr, *it = nullptr;
-        ok = pengk_malloc(context(), st->words_cap * sizeof(uint64_t), &w) == PENGK_OK &&
-             pengk_malloc(context(), st->items_cap * sizeof(uint64_t), &it) == PENGK_OK;
-        st->in.d_words = (uint64_t*)w;
-        st->in.d_items = (uint64_t*)it;
-      }
-      if (ok && (word_at + pk.n_words > st->words_cap || item_at + pk.n_items > st->items_cap)) {
-        stream_fail(st, "packed chunks exceed the bounds computed from the file size");
-        ok = false;
-      }
-      if (ok && pengk_append_packed(context(), st->in.d_words, word_at, st->in.d_items, item_at, &pk) != PENGK_OK) ok = false;
-      if (!ok) stream_fail(st, std::string("upload of a packed chunk failed: ") + pengk_last_error());
-      word_at += pk.n_words;
-      item_at += pk.n_items;
-      st->in.n_words = word_at;
-      st->in.n_items = item_at;
-      pengk_packed_free(&pk);
-    }
-  });
+  st->uploader = std::thread(upload_loop, st);
 }
 
 void sink_chunk(void* user, size_t, const SequenceChunk& c) {
   Stream* st = (Stream*)user;
-  if (c.n == 0) return;
+  if (c.n == 0 || !st->started) return;
   pengk_packed pk;
-  if (pengk_pack_threads(c.codes, c.offs.data(), (int64_t)c.n, st->in.W, 0, 1, &pk) != PENGK_OK) {
-    stream_fail(st, std::string("pengk_pack failed: ") + pengk_last_error());
+  if (pengk_pack_append(c.codes, c.offs.data(), (int64_t)c.n, st->in.W, 0, &st->target, &pk) != PENGK_OK) {
+    stream_fail(st, std::string("pengk_pack_append failed: ") + pengk_last_error());
     return;
   }
+  bool filled = false;
   {
     std::lock_guard<std::mutex> lock(st->mu);
     st->in.item_windows = pk.item_windows;
@@ -202,9 +256,17 @@ void sink_chunk(void* user, size_t, const SequenceChunk& c) {
     st->in.max_bin_bound += pk.max_bin_bound;
     st->in.all_whole &= pk.all_whole;
     for (int i = 0; i < 84; ++i) st->in.bg_counts[i] += pk.bg_counts[i];
-    st->ready.push_back(pk);
+    uint64_t w = (uint64_t)(pk.words - st->target.words);
+    const uint64_t end = w + pk.n_words;
+    if (end > st->reserved_end) st->reserved_end = end;
+    while (w < end) {  // the chunk's words, slab by slab
+      const uint64_t slab = w / SLAB_WORDS, upto = std::min(end, (slab + 1) * SLAB_WORDS);
+      st->slab_fill[slab] += upto - w;
+      filled |= st->slab_fill[slab] == SLAB_WORDS;
+      w = upto;
+    }
   }
-  st->cv.notify_one();
+  if (filled) st->cv.notify_one();
 }
 }  // namespace
 
@@ -224,18 +286,24 @@ void begin_streaming_pack(int W) {
 
 const PackedInput* finish_streaming_pack(SequenceSet* set) {
   Stream* st = g_stream;
-  if (!st || !st->started) return nullptr;
-  {
-    std::lock_guard<std::mutex> lock(st->mu);
-    st->done = true;
+  if (!st) return nullptr;
+  if (st->started) {
+    {
+      std::lock_guard<std::mutex> lock(st->mu);
+      st->done = true;
+    }
+    st->cv.notify_all();
+    st->uploader.join();
   }
-  st->cv.notify_all();
-  st->uploader.join();
   if (!st->error.empty()) {
     std::cerr << "Error: " << st->error << std::endl;
     exit(1);
   }
   st->set = set;
+  // the host copies have done their duty
+  if (st->target.words) munmap(st->target.words, st->words_bytes);
+  if (st->target.items) munmap(st->target.items, st->items_bytes);
+  st->target.words = st->target.items = nullptr;
   if (!st->in.d_words) return nullptr;  // no records at all on this rank: the staged path handles the empty shard
   return &st->in;
 }

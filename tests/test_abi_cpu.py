@@ -211,3 +211,57 @@ def test_packer_one_pass_path_gives_way_on_any_irregular_sequence(monkeypatch):
     monkeypatch.setenv("PENGK_PACK_GENERAL", "0")
     b = pk.Packed(codes2, offs2, W, 64)
     assert a.all_whole == 0 and b.all_whole == 0 and a.words.tobytes() == b.words.tobytes() and a.items.tobytes() == b.items.tobytes()
+
+
+class PackTarget(pk.C.Structure):
+    _fields_ = [("words", pk.C.POINTER(pk.C.c_uint64)), ("words_cap", pk.C.c_uint64), ("items", pk.C.POINTER(pk.C.c_uint64)),
+                ("items_cap", pk.C.c_uint64), ("word_cursor", pk.C.c_uint64), ("item_cursor", pk.C.c_uint64)]
+
+
+@pytest.mark.parametrize("irregular", [False, True])
+def test_pack_append_collects_chunks_like_separate_packs(irregular):
+    """pengk_pack_append (the CLI's streaming ingest: chunks of the input packed from many threads into ONE pair of
+    buffers) -- every chunk's region holds what pengk_pack makes of the chunk alone, its items carry absolute stream
+    offsets, the figures (windows, bounds, background counters) are the chunk's; cursors advance atomically."""
+    import threading
+    C = pk.C
+    W, L, n_chunks, per = 10, 150, 12, 700
+    rng = np.random.default_rng(3)
+    chunks = []
+    for c in range(n_chunks):
+        codes = rng.integers(1, 5, size=per * L).astype(np.uint8)
+        offs = np.arange(per + 1, dtype=np.int64) * L
+        if irregular and c % 3 == 1:  # invalid bases / a short record: this chunk takes the general path
+            codes[rng.integers(0, codes.size, 40)] = 0
+        chunks.append((codes, offs))
+    words = np.zeros(n_chunks * (per * L // 32 + 8) + 16, np.uint64)
+    items = np.zeros(n_chunks * per * 2 + 16, np.uint64)
+    tg = PackTarget(words.ctypes.data_as(C.POINTER(C.c_uint64)), words.size, items.ctypes.data_as(C.POINTER(C.c_uint64)), items.size, 0, 0)
+    res = [None] * n_chunks
+
+    def work(c):
+        st = pk.PackedStruct()
+        rc = pk.lib().pengk_pack_append(chunks[c][0].ctypes.data, chunks[c][1].ctypes.data, per, W, 0, C.byref(tg), C.byref(st))
+        res[c] = (rc, st)
+
+    th = [threading.Thread(target=work, args=(c,)) for c in range(n_chunks)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    used_w, used_i = 0, 0
+    for c, (rc, st) in enumerate(res):
+        assert rc == 0
+        alone = pk.Packed(chunks[c][0], chunks[c][1], W)
+        w0 = (C.addressof(st.words.contents) - words.ctypes.data) // 8
+        i0 = (C.addressof(st.items.contents) - items.ctypes.data) // 8 if st.n_items else 0
+        assert np.array_equal(words[w0:w0 + len(alone.words)], alone.words) and not words[w0 + len(alone.words):w0 + st.n_words].any()
+        assert st.n_items == len(alone.items)
+        assert np.array_equal(items[i0:i0 + st.n_items], alone.items + np.uint64(32 * w0))
+        assert (st.n_windows, st.max_bin_bound, st.all_whole) == (alone.n_windows, alone.max_bin_bound, alone.all_whole)
+        assert list(st.bg_counts) == alone.bg_counts.tolist()
+        used_w += st.n_words
+        used_i += st.n_items
+    assert tg.word_cursor == used_w and tg.item_cursor == used_i
+    # a full buffer is an error, not an overrun
+    small = PackTarget(words.ctypes.data_as(C.POINTER(C.c_uint64)), 8, items.ctypes.data_as(C.POINTER(C.c_uint64)), items.size, 0, 0)
+    st = pk.PackedStruct()
+    assert pk.lib().pengk_pack_append(chunks[0][0].ctypes.data, chunks[0][1].ctypes.data, per, W, 0, C.byref(small), C.byref(st)) == pk.ERR_RANGE
