@@ -295,7 +295,11 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
             if (BOTH) rc_u = __builtin_amdgcn_ubfe(rview[jr], 2u * (uint32_t)(k - jr * G::PER), 2u * W);
           }
           const uint32_t can = BOTH ? min(id_u, rc_u) : id_u;
+#ifdef PENGK_ABLATE_NOSUPPRESS  // timing experiment only (WRONG counts on repeats): what a free repeat pre-filter could gain at most
+          const uint32_t key = can;
+#else
           const uint32_t key = Suppress<W>::apply(can, ring, u);  // INVALID_ID iff one of the last W-1 counted ids
+#endif
           ring[u] = key;
           if (FULL) {
             if (BG && (u & 1)) {  // 4-mer ending on base u: bases u-3 .. u
