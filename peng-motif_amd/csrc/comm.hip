@@ -25,6 +25,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <poll.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
@@ -63,10 +64,23 @@ Rccl g_rccl;
 
 int load_rccl() {
   if (g_rccl.handle) return PENGK_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
+  // A host process that already carries an RCCL (PyTorch ships its own librccl.so and loads it with the process) must
+  // not get a second instance beside it: two copies of the library would each keep their own transports, shared-memory
+  // segments and IPC state on the same GPUs.  Take the copy that is mapped, if there is one.
+  if (FILE* maps = fopen("/proc/self/maps", "r")) {
+    char line[1024];
+    while (!h && fgets(line, sizeof line, maps)) {
+      char* path = strchr(line, '/');
+      if (!path || !strstr(path, "librccl")) continue;
+      path[strcspn(path, "\n")] = 0;
+      h = dlopen(path, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    }
+    fclose(maps);
+  }
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
   if (!h) return fail(PENGK_ERR_DEVICE, "librccl not found: %s", dlerror());
 #define PENGK_SYM(field, name)                                            \
   do {                                                                    \
