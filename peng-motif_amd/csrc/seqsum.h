@@ -235,7 +235,7 @@ __device__ __forceinline__ float fold_block(const Row& mine, uint32_t lane, floa
 //
 // 1 + FETCH_WAVES waves per chain (a workgroup of CHAIN_THREADS threads, every thread calls fold_chain): moving a
 // block through a wave -- sixteen 16-byte loads, sixteen LDS writes, the wait for them -- takes as long as evaluating
-// it, so the waves behind wave 0 only fetch, 1 / FETCH_WAVES of a block each, while wave 0 only evaluates.
+// it, so the waves behind wave 0 only fetch (whole blocks, in turn), while wave 0 only evaluates.
 // ONE row buffer in LDS (17 KiB: eight chains per CU, two evaluating waves per SIMD that fill each other's waits):
 //   barrier B(i)   block i is in LDS            wave 0 reads its rows into registers (the whole block: 64 x 64 terms)
 //   barrier A(i)   block i is in registers      the fetchers deposit block i + 1 (its loads were issued during block
@@ -244,10 +244,20 @@ __device__ __forceinline__ float fold_block(const Row& mine, uint32_t lane, floa
 // CHECK: the fetching waves look at every term; a chain with a negative / non-finite term is summed by the plain loop
 // `serial`.  The flag is written in front of B(i) and read by every wave between B(i) and A(i); the next write comes
 // behind A(i): all waves leave at the same i.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's GLOBAL loads (s_waitcnt
+// vmcnt(0) in front of s_barrier): a fetch wave that has just issued the loads of a later block would stand at the
+// barrier until they have landed, and everybody with it -- the memory latency the prefetch is there to hide.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #ifndef PENGK_FETCH_WAVES
-#define PENGK_FETCH_WAVES 1  // measured (16 PWMs x 10 iterations, W = 10): 1 -> 1.02 ms, 2 -> 1.09, 4 -> 1.11
+#define PENGK_FETCH_WAVES 1
 #endif
-constexpr uint32_t FETCH_WAVES = PENGK_FETCH_WAVES;  // each fetches 1 / FETCH_WAVES of every block
+// FETCH_WAVES fetching waves take the blocks in turn (wave q moves the blocks i = q mod FETCH_WAVES, whole): the loads
+// of a block are issued FETCH_WAVES block times before it is needed.  Measured with the LDS-only barrier, i.e. with
+// loads that really stay in flight across steps (16 PWMs x 10 iterations, W = 10): 1 -> 0.94 ms, 2 -> 0.98, 3 -> 0.99,
+// 4 -> 1.32 -- a step is NOT waiting for its loads; it takes what the evaluating wave's dependent additions take
+// (profiles/r03_em_experiments.log).
+constexpr uint32_t FETCH_WAVES = PENGK_FETCH_WAVES;
 constexpr uint32_t CHAIN_THREADS = 64u * (1u + FETCH_WAVES);
 constexpr uint32_t CHAIN_LDS_FLOATS = LDS_FLOATS + 4u;  // the row buffer + the flag word
 template <class Source, bool CHECK>
@@ -255,7 +265,7 @@ __device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks
   const uint32_t lane = thread & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(thread >> 6));  // wave-uniform
   const bool fetcher = wave != 0u;
-  const uint32_t part = wave - 1u;  // which share of a block this fetch wave moves
+  const uint32_t q = wave - 1u;  // a fetch wave's turn
   volatile uint32_t* bad = reinterpret_cast<volatile uint32_t*>(lds + LDS_FLOATS);
   if (CHECK) {
     if (thread == 0) *bad = 0u;
@@ -265,28 +275,30 @@ __device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks
   float s = 0.0f;
   bool fallback = false;
   if (fetcher) {
-    float R[64 / FETCH_WAVES];
-    src.template load<FETCH_WAVES>(0u, part, lane, R);
+    float R[64];
+    if (q < n_blocks) src.template load<1>(q, 0u, lane, R);
 #pragma unroll 1
     for (uint32_t i = 0; i < n_blocks; ++i) {
-      if (CHECK) {
-        uint32_t m = 0;
+      if (i % FETCH_WAVES == q) {
+        if (CHECK) {
+          uint32_t m = 0;
 #pragma unroll
-        for (int k = 0; k < (int)(64 / FETCH_WAVES); ++k) m = max(m, bits(R[k]));
-        if (__builtin_amdgcn_ballot_w64(m > 0x7F7FFFFFu) && lane == 0) *bad = 1u;
+          for (int k = 0; k < 64; ++k) m = max(m, bits(R[k]));
+          if (__builtin_amdgcn_ballot_w64(m > 0x7F7FFFFFu) && lane == 0) *bad = 1u;
+        }
+        const unsigned long long c0 = PENGK_CLOCK();
+        src.template deposit<1>(0u, lane, R, lds);
+        if (i + FETCH_WAVES < n_blocks) src.template load<1>(i + FETCH_WAVES, 0u, lane, R);
+        PENGK_STAT_ADD(2, PENGK_CLOCK() - c0);
       }
-      const unsigned long long c0 = PENGK_CLOCK();
-      src.template deposit<FETCH_WAVES>(part, lane, R, lds);
-      if (i + 1u < n_blocks) src.template load<FETCH_WAVES>(i + 1u, part, lane, R);
-      PENGK_STAT_ADD(2, PENGK_CLOCK() - c0);
-      __syncthreads();  // B(i)
+      lds_barrier();  // B(i)
       if (CHECK && *bad) break;
-      __syncthreads();  // A(i)
+      lds_barrier();  // A(i)
     }
   } else {
 #pragma unroll 1
     for (uint32_t i = 0; i < n_blocks; ++i) {
-      __syncthreads();  // B(i)
+      lds_barrier();  // B(i)
       if (CHECK && *bad) {
         fallback = true;
         break;
@@ -295,7 +307,7 @@ __device__ __forceinline__ float fold_chain(const Source& src, uint32_t n_blocks
       Row mine;
       mine.read(lds + lane * SEG_STRIDE);
       PENGK_STAT_ADD(4, PENGK_CLOCK() - k0);
-      __syncthreads();  // A(i)
+      lds_barrier();  // A(i)
       const unsigned long long c0 = PENGK_CLOCK();
       s = fold_block(mine, lane, s, st);
       PENGK_STAT_ADD(0, 1);
