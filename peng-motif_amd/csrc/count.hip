@@ -429,6 +429,42 @@ struct Split12L2 {
   __host__ __device__ static inline bool valid(uint32_t p2) { return p2 != KEY_INVALID; }
 };
 
+// W = 14 (28-bit ids) needs 2^13 buckets of 2^15 bins: three levels, bucket bits again from the middle of what is left.
+//   level 1: bucket1 = id bits [10,15), 23-bit payload1 (32-bit keys)
+//   level 2: bucket2 = payload1 bits [9,13), 19-bit payload2 (32-bit keys)
+//   level 3: bucket3 = payload2 bits [8,12), 15-bit payload3 (16-bit keys) -- the second level of W = 12
+// A suppressed window (INVALID_ID) and the padding entries are all ones in every payload bit at every level: their
+// bucket bits select the last bucket, their payloads fail valid() and end as KEY_INVALID, which pass B skips.
+struct Split14L1 {
+  static constexpr uint32_t NB = 32;
+  __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> 10) & 31u; }
+  __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & 0x3FFu) | ((id >> 15) << 10); }
+  __host__ __device__ static inline uint32_t join(uint32_t b1, uint32_t p1, uint32_t /*outer*/ = 0) { return (p1 & 0x3FFu) | (b1 << 10) | ((p1 >> 10) << 15); }
+  __host__ __device__ static inline bool valid(uint32_t p1) { return p1 < (1u << 23); }
+};
+struct Split14L2 {
+  static constexpr int NBITS = 4;
+  static constexpr uint32_t NB = 16;
+  __host__ __device__ static inline uint32_t bucket(uint32_t p1) { return (p1 >> 9) & 15u; }
+  __host__ __device__ static inline uint32_t payload(uint32_t p1) { return (p1 & 0x1FFu) | ((p1 >> 13) << 9); }
+  // (bucket2, payload2) of level-1 bucket `outer` -> 28-bit id
+  __host__ __device__ static inline uint32_t join(uint32_t b2, uint32_t p2, uint32_t outer) {
+    return Split14L1::join(outer, (p2 & 0x1FFu) | (b2 << 9) | ((p2 >> 9) << 13));
+  }
+  __host__ __device__ static inline bool valid(uint32_t p2) { return p2 < (1u << 19); }
+};
+struct Split14L3 {
+  static constexpr int NBITS = 4;
+  static constexpr uint32_t NB = 16;
+  __host__ __device__ static inline uint32_t bucket(uint32_t p2) { return (p2 >> 8) & 15u; }
+  __host__ __device__ static inline uint32_t payload(uint32_t p2) { return (p2 & 0xFFu) | ((p2 >> 12) << 8); }
+  // (bucket3, payload3) of the level-1 / level-2 buckets outer = b1 * 16 + b2 -> 28-bit id
+  __host__ __device__ static inline uint32_t join(uint32_t b3, uint32_t p3, uint32_t outer) {
+    return Split14L2::join(outer & 15u, (p3 & 0xFFu) | (b3 << 8) | ((p3 >> 8) << 12), outer >> 4);
+  }
+  __host__ __device__ static inline bool valid(uint32_t p3) { return p3 != KEY_INVALID; }
+};
+
 // One row per (wave, bucket): the ring and, behind it, its counter.  The odd row stride (65 dwords) spreads rows over
 // the LDS banks: rings fill at the same pace, and with a 256-byte stride equal fill levels would put every lane of
 // the 16-bit ring write -- and every counter -- on the same few banks.
@@ -685,6 +721,80 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
     }
   }
   e.drain();
+}
+
+// ---- three-level partition (W = 14) ------------------------------------------------------------------------
+typedef ScatterEmit<Split14L1, 5, SCATTER12_WPW, uint32_t> Scatter14Emit;
+
+template <bool BOTH, bool BG>
+__global__ __launch_bounds__(64 * SCATTER12_WPW) void count_scatter14_kernel(const uint32_t* __restrict__ words32,
+                                                              const uint64_t* __restrict__ items, uint32_t n_items,
+                                                              uint32_t* __restrict__ keys, uint32_t slice_cap,
+                                                              uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
+                                                              unsigned long long* __restrict__ ltot,
+                                                              uint32_t* __restrict__ defer, uint32_t* __restrict__ bg_partials) {
+  Scatter14Emit::init_lds();
+  bg_begin<BG>();
+  __syncthreads();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  Scatter14Emit e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * (uint32_t)SCATTER12_WPW + wave, 0u};
+  e.bind();
+  scan_items<14, BOTH, BG>(words32, items, n_items, ltot, defer, e);
+  e.drain();
+  bg_end<BG>(bg_partials);
+}
+
+// A middle / last level: a workgroup belongs to ONE bucket of the level above -- composite index o = blockIdx.x / bpb,
+// input bucket o % NB_IN of the slices written by the workgroups that served o / NB_IN (`slices_per_group` producer
+// waves each; 0 = every producer wave holds a slice of every input bucket: the level below the scan) -- streams those
+// slices (256 keys per step, 16-byte loads one step ahead) and re-scatters them with the emitter of pass A.
+template <class KS, class E_OUT, uint32_t NB_IN>
+__global__ __launch_bounds__(256) void count_rescatter_kernel(const uint32_t* __restrict__ keys_in, uint32_t cap_in,
+                                                              const uint32_t* __restrict__ fill_in, uint32_t n_slices_in,
+                                                              uint32_t slices_per_group, uint32_t bpb, E_OUT* __restrict__ keys_out,
+                                                              uint32_t cap_out, uint32_t* __restrict__ fill_out,
+                                                              uint32_t* __restrict__ hist) {
+  typedef ScatterEmit<KS, KS::NBITS, 4, E_OUT> Emit;
+  Emit::init_lds();
+  __syncthreads();
+  const uint32_t o = blockIdx.x / bpb, j = blockIdx.x % bpb;
+  const uint32_t b_in = slices_per_group ? o % NB_IN : o;
+  const uint32_t slice0 = slices_per_group ? (o / NB_IN) * slices_per_group : 0u;
+  const uint32_t n_in = slices_per_group ? slices_per_group : n_slices_in;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+  Emit e{keys_out, cap_out, fill_out, hist, wave, lane, blockIdx.x * 4u + wave, o};
+  e.bind();
+  const uint32_t per = (n_in + bpb - 1) / bpb;
+  const uint32_t first = j * per, last = min(n_in, first + per);
+  for (uint32_t t = first + wave; t < last; t += 4) {
+    const uint32_t sl = slice0 + t;
+    const uint32_t n = fill_in[(size_t)sl * NB_IN + b_in];  // multiple of GROUP
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 pad = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const u4* src4 = reinterpret_cast<const u4*>(keys_in + ((size_t)sl * NB_IN + b_in) * cap_in);
+    const uint32_t n4 = n / 4u;
+    u4 nxt = lane < n4 ? __builtin_nontemporal_load(&src4[lane]) : pad;
+    for (uint32_t i = 0; i < n4; i += 64) {  // wave-uniform trip count
+      const u4 k = nxt;
+      nxt = (i + 64u + lane < n4) ? __builtin_nontemporal_load(&src4[i + 64u + lane]) : pad;
+      e.full(k.x);
+      e.full(k.y);
+      e.full(k.z);
+      e.full(k.w);
+    }
+  }
+  e.drain();
+}
+
+// W = 14: table[id] += temp[(bucket1 * 16 + bucket2) * 16 + bucket3][payload3]
+__global__ __launch_bounds__(256) void count_gather14_kernel(const uint32_t* __restrict__ temp, uint32_t* __restrict__ hist) {
+  const uint32_t np = 1u << 28;
+  for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
+    const uint32_t p1 = Split14L1::payload(x), p2 = Split14L2::payload(p1);
+    const uint32_t fb = (Split14L1::bucket(x) * 16u + Split14L2::bucket(p1)) * 16u + Split14L3::bucket(p2);
+    const uint32_t v = temp[((size_t)fb << PAYLOAD_BITS) | Split14L3::payload(p2)];
+    if (v) hist[x] += v;
+  }
 }
 
 // One workgroup = 16 waves = part of one bucket: waves walk the (bucket, producer-wave) slices of their share.
@@ -1226,6 +1336,85 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   return PENGK_OK;
 }
 
+// W = 14: scan -> 32 buckets of 32-bit keys -> 16 each of 32-bit keys -> 16 each of 16-bit keys -> 8192 LDS histograms.
+// 20 B per window through HBM (4 + 4 written and read, 2 written and read) instead of one device-scope atomic per window
+// on a 1 GiB table.
+int launch_partition14(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items, uint64_t* d_bg) {
+  const size_t np = (size_t)1 << 28;
+  const uint32_t* w32 = (const uint32_t*)ctx->d_words;
+  constexpr uint32_t TPB1 = 64u * SCATTER12_WPW;
+  const uint32_t blocks_needed = (n_items + TPB1 - 1) / TPB1;
+  constexpr uint32_t lds_per_wg1 = (uint32_t)(sizeof(ScatterShared<5, SCATTER12_WPW, uint32_t>) + sizeof(BgLds) + 511u) & ~511u;
+  const uint32_t max_blocks = (uint32_t)ctx->num_cu * ((160u * 1024u) / lds_per_wg1);
+  const uint32_t blocks1 = blocks_needed < max_blocks ? blocks_needed : max_blocks;
+  const uint32_t n_waves1 = blocks1 * (uint32_t)SCATTER12_WPW;
+  const uint64_t windows = ctx->n_windows_hint ? ctx->n_windows_hint : ctx->n_items * (uint64_t)ctx->item_windows;
+  auto cap_of = [&](uint64_t slices, uint64_t slack) {  // 1.5 x the uniform share of a (wave, bucket) slice, whole groups
+    uint64_t c = windows / slices;
+    c = c + c / 2 + slack;
+    if (ctx->key_cap_override) c = ctx->key_cap_override;
+    return (c + 63) / 64 * 64;
+  };
+  // level 2: bpb1 workgroups per level-1 bucket; level 3: bpb2 workgroups per (level-1, level-2) bucket
+  uint32_t bpb1 = ((uint32_t)ctx->num_cu * 8u + 31u) / 32u;
+  if (bpb1 > n_waves1) bpb1 = n_waves1;
+  if (bpb1 < 1) bpb1 = 1;
+  const uint32_t blocks2 = 32u * bpb1, n_waves2 = blocks2 * 4u;
+  uint32_t bpb2 = ((uint32_t)ctx->num_cu * 8u + 511u) / 512u;
+  if (bpb2 > bpb1 * 4u) bpb2 = bpb1 * 4u;
+  if (bpb2 < 1) bpb2 = 1;
+  const uint32_t blocks3 = 512u * bpb2, n_waves3 = blocks3 * 4u;
+  const uint64_t cap1_64 = cap_of(32ull * n_waves1, 256), cap2_64 = cap_of(16ull * n_waves2, 256), cap3_64 = cap_of(16ull * n_waves3, 256);
+  if (cap1_64 * 32ull >= (1ull << 30) || cap2_64 * 16ull >= (1ull << 30) || cap3_64 * 16ull >= (1ull << 31))  // 32-bit byte offsets
+    return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
+  const uint32_t cap1 = (uint32_t)cap1_64, cap2 = (uint32_t)cap2_64, cap3 = (uint32_t)cap3_64;
+  const size_t bytes1 = (size_t)n_waves1 * 32u * cap1 * sizeof(uint32_t);
+  const size_t bytes2 = (size_t)n_waves2 * 16u * cap2 * sizeof(uint32_t);
+  const size_t bytes3 = (size_t)n_waves3 * 16u * cap3 * sizeof(uint16_t);
+  int rc = ensure_scratch(ctx, &ctx->d_keys, &ctx->keys_bytes, bytes1 + bytes2 + bytes3);
+  if (rc) return rc;
+  uint32_t* keys1 = (uint32_t*)ctx->d_keys;
+  uint32_t* keys2 = (uint32_t*)((char*)ctx->d_keys + bytes1);
+  uint16_t* keys3 = (uint16_t*)((char*)ctx->d_keys + bytes1 + bytes2);
+  const size_t f1 = ((size_t)n_waves1 * 32u + 63) / 64 * 64, f2 = ((size_t)n_waves2 * 16u + 63) / 64 * 64,
+               f3 = ((size_t)n_waves3 * 16u + 63) / 64 * 64;
+  const size_t aux_need = (f1 + f2 + f3 + np) * sizeof(uint32_t);
+  rc = ensure_scratch(ctx, &ctx->d_count_aux, &ctx->count_aux_bytes, aux_need);
+  if (rc) return rc;
+  uint32_t* fill1 = (uint32_t*)ctx->d_count_aux;
+  uint32_t* fill2 = fill1 + f1;
+  uint32_t* fill3 = fill2 + f2;
+  uint32_t* temp = fill3 + f3;
+  PENGK_HIP(hipMemsetAsync(ctx->d_count_aux, 0, aux_need, ctx->stream));
+  unsigned long long* lt = (unsigned long long*)d_ltot;
+  uint32_t* bgp = nullptr;
+  if (d_bg) {
+    rc = bg_partials_buffer(ctx, blocks1, &bgp);
+    if (rc) return rc;
+  }
+#define TA_S14(B, G) B, G
+  PENGK_LAUNCH_BB(count_scatter14_kernel, TA_S14, both, d_bg != nullptr, dim3(blocks1), dim3(TPB1), w32, ctx->d_items, n_items, keys1,
+                  cap1, fill1, d_counts, lt, ctx->d_defer, bgp);
+#undef TA_S14
+  PENGK_HIP(hipGetLastError());
+  if (d_bg) {
+    rc = bg_finish_fused(ctx, blocks1, d_bg);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL((count_rescatter_kernel<Split14L2, uint32_t, 32u>), dim3(blocks2), dim3(256), 0, ctx->stream, keys1, cap1, fill1,
+                     n_waves1, 0u, bpb1, keys2, cap2, fill2, d_counts);
+  PENGK_HIP(hipGetLastError());
+  hipLaunchKernelGGL((count_rescatter_kernel<Split14L3, uint16_t, 16u>), dim3(blocks3), dim3(256), 0, ctx->stream, keys2, cap2, fill2,
+                     n_waves2, bpb1 * 4u, bpb2, keys3, cap3, fill3, d_counts);
+  PENGK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(count_hist_kernel, dim3(8192), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys3, cap3, n_waves3, 16u, fill3, 1u,
+                     temp, bpb2 * 4u);
+  PENGK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(count_gather14_kernel, dim3(8192), dim3(256), 0, ctx->stream, temp, d_counts);
+  PENGK_HIP(hipGetLastError());
+  return PENGK_OK;
+}
+
 template <int W>
 int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint64_t* d_bg) {
   const uint32_t n_items = (uint32_t)ctx->n_items;
@@ -1234,11 +1423,14 @@ int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_lto
     return PENGK_OK;
   }
   int impl = ctx->count_impl;
-  constexpr bool can_partition = (W == 8 || W == 10 || W == 12);
+  constexpr bool can_partition = (W == 8 || W == 10 || W == 12 || W == 14);
   if (impl == 0) impl = can_partition ? 2 : 1;
-  if (impl == 2 && !can_partition) return fail(PENGK_ERR_UNSUPPORTED, "partitioned count is built for W = 8, 10 and 12 only");
+  if (impl == 2 && !can_partition) return fail(PENGK_ERR_UNSUPPORTED, "partitioned count is built for W = 8 .. 14 only");
   int rc;
-  if constexpr (W == 12) {
+  if constexpr (W == 14) {
+    rc = impl == 2 ? launch_partition14(ctx, both, d_counts, d_ltot, n_items, d_bg)
+                   : launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items, d_bg);
+  } else if constexpr (W == 12) {
     rc = impl == 2 ? launch_partition12(ctx, both, d_counts, d_ltot, n_items, d_bg)
                    : launch_direct_w<W>(ctx, both, d_counts, d_ltot, n_items, d_bg);
   } else if constexpr (can_partition) {

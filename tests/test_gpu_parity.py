@@ -256,6 +256,39 @@ def test_partitioned_count_survives_a_full_bucket_region(ctx):
         ctx.set_option("key_cap_override", 0)
 
 
+@pytest.mark.parametrize("both", [True, False])
+def test_partitioned_count_w14_three_levels(ctx, both):
+    """W = 14 (2^28 bins = 2^13 LDS histograms): three partition levels -- scan -> 32 buckets of 32-bit keys -> 16 each
+    of 32-bit keys -> 16 each of 16-bit keys -> pass B.  Against the direct (one atomic per window) emitter, which
+    test_count_low_complexity_long_sequences pins to the oracle at W = 14: random sequences, the many-lanes-on-one-bucket
+    sets (identical sequences, a period-13 repeat, poly-T), and slices forced to overflow at every level."""
+    W = 14
+    rng = np.random.default_rng(14)
+    n, L = 30000, 180
+    codes = rng.integers(1, 5, size=n * L).astype(np.uint8)
+    codes[rng.integers(0, codes.size, 200)] = 0  # a few N: more than one run per sequence, items that start mid-sequence
+    cases = {"random_30000x180": (codes, np.arange(n + 1, dtype=np.int64) * L, 0)}
+    for name, (c, o) in _same_bucket_sets(W).items():
+        cases[name] = (c, o, 0)
+    cases["random_overflowing_slices"] = (codes, np.arange(n + 1, dtype=np.int64) * L, 64)
+    for name, (c, o, cap) in cases.items():
+        ctx.upload(pk.Packed(c, o, W))
+        ctx.set_option("count_impl", 1)
+        try:
+            want, lt1 = ctx.count(both)
+            want, lt1 = want.to_host().copy(), int(lt1.to_host()[0])
+            ctx.set_option("count_impl", 2)
+            ctx.set_option("key_cap_override", cap)
+            got, lt2 = ctx.count(both)
+            assert int(lt2.to_host()[0]) == lt1, name
+            got = got.to_host()
+            assert np.array_equal(got, want), "%s: %d mismatching bins" % (name, int((got != want).sum()))
+            assert int(got.sum()) > 0
+        finally:
+            ctx.set_option("count_impl", 0)
+            ctx.set_option("key_cap_override", 0)
+
+
 def low_complexity_set(seed, n, L):
     rng = np.random.default_rng(seed)
     seqs = []
@@ -328,8 +361,8 @@ def test_device_bg_count_matches_packer_and_oracle(ctx, golden_dir):
 def test_fused_bg_count(ctx, golden_dir, W, M, impl):
     """pengk_count_bg: the 3-mer bins collected inside the count scan == the packer's / oracle's counts,
     and the count table is unchanged.  M = 64 splits runs (continuing items must not recount their prologue)."""
-    if impl == 2 and W not in (8, 10, 12):
-        pytest.skip("partitioned count is built for W = 8, 10, 12")
+    if impl == 2 and W not in (8, 10, 12, 14):
+        pytest.skip("partitioned count is built for W = 8 .. 14")
     codes, offs = po.read_fasta(os.path.join(golden_dir, "MafK.fasta"))
     codes, offs = codes[:offs[600]], offs[:601]
     p = pk.Packed(codes, offs, W, M)
