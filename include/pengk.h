@@ -71,7 +71,7 @@ void* pengk_stream(pengk_ctx* ctx);
 int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
 
 /* Tunables / introspection.  Options: "count_impl" 0 = auto, 1 = direct global atomics, 2 = partitioned LDS
- * histograms (W = 8, 10, 12); "n_windows_hint" = total windows of the attached items (sizes the key buffer
+ * histograms (W = 8 .. 14); "n_windows_hint" = total windows of the attached items (sizes the key buffer
  * tightly; set it after pengk_set_sequences); "key_cap_override" (test hook) entries per bucket region of the
  * partitioned count, 0 = automatic; "iupac_group_bytes" (test hook) scratch budget for one group of large
  * patterns in pengk_iupac_aggregate, 0 = 1 GiB; "em_fast" 1 (default) / 0 / 2, see pengk_em.  Info: "deferred_items" (of the last pengk_count;
@@ -170,9 +170,9 @@ int pengk_synth_sequences(pengk_ctx* ctx, uint64_t seed, uint64_t seq0, uint64_t
  * only (run pengk_mirror_counts for the reference's twin copy, :387-392).  d_ltot: uint64 scalar,
  * overwritten with the number of visited windows.  The non-overlap rule (:361-366) is applied
  * exactly, with 64-bit positions.  Counts of different shards add (the rule is per sequence).
- * Emitters: W = 8, 10, 12 use the partitioned LDS-histogram count; W = 4, 6 (tables that are contended in any form)
- * and W = 14 (2^28 bins = 2^13 LDS histograms: a third partition level that is not built -- the reference itself
- * advises W <= 12, README.md:119) count with one device-scope atomic per window, about 20x slower per base. */
+ * Emitters: W = 8 .. 14 use the partitioned LDS-histogram count (one partition level at W = 8, 10; two at W = 12; three
+ * at W = 14: 2^28 bins = 2^13 LDS histograms -- the reference itself advises W <= 12, README.md:119); W = 4, 6 (tables
+ * that are contended in any form) count with one device-scope atomic per window. */
 int pengk_count(pengk_ctx* ctx, int both_strands, uint32_t* d_counts, uint64_t* d_ltot);
 int pengk_mirror_counts(pengk_ctx* ctx, int W, uint32_t* d_counts);
 /* pengk_count with K1b fused into the same scan (the rolling id's top three digits are the 3-mer ending at
