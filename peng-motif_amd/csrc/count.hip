@@ -408,39 +408,47 @@ struct KeySplit {
 //   level 1: bucket1 = id bits [8,13), 19-bit payload1 = the rest squeezed together (32-bit keys)
 //   level 2: bucket2 = payload1 bits [8,12), 15-bit payload2 = the rest (16-bit keys)
 // Again the bucket bits come from the middle of the id (see KeySplit).
+#ifndef PENGK_W12_L1_BITS
+#define PENGK_W12_L1_BITS 4  // bucket bits of level 1 (level 2 takes 9 - that).  Measured on a 12.5M x 200 bp shard: 5 + 4 -> 8.26 ms,
+                             // 4 + 5 -> 7.2 (the scan's 32-bit rings are 8.3 instead of 16.5 KiB per wave: 16 instead of 9
+                             // waves per CU for the kernel that is bound by what it issues), 3 + 6 -> 8.86
+#endif
 struct Split12L1 {
-  static constexpr uint32_t NB = 32;
-  __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> 8) & 31u; }
-  __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & 0xFFu) | ((id >> 13) << 8); }
-  __host__ __device__ static inline uint32_t join(uint32_t b1, uint32_t p1, uint32_t /*outer*/ = 0) { return (p1 & 0xFFu) | (b1 << 8) | ((p1 >> 8) << 13); }
-  // a 19-bit payload; INVALID_ID and padding entries carry higher bits (and travel on as KEY_INVALID through level 2)
-  __host__ __device__ static inline bool valid(uint32_t p1) { return p1 < (1u << 19); }
+  static constexpr int NBITS = PENGK_W12_L1_BITS;
+  static constexpr uint32_t NB = 1u << NBITS;
+  static constexpr uint32_t PBITS = 24 - NBITS;  // bits of payload1
+  __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> 8) & (NB - 1u); }
+  __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & 0xFFu) | ((id >> (8 + NBITS)) << 8); }
+  __host__ __device__ static inline uint32_t join(uint32_t b1, uint32_t p1, uint32_t /*outer*/ = 0) { return (p1 & 0xFFu) | (b1 << 8) | ((p1 >> 8) << (8 + NBITS)); }
+  // a payload of PBITS bits; INVALID_ID and padding entries carry higher bits (and travel on as KEY_INVALID through level 2)
+  __host__ __device__ static inline bool valid(uint32_t p1) { return p1 < (1u << PBITS); }
 };
 struct Split12L2 {
-  static constexpr int NBITS = 4;
-  static constexpr uint32_t NB = 16;
-  __host__ __device__ static inline uint32_t bucket(uint32_t p1) { return (p1 >> 8) & 15u; }
-  __host__ __device__ static inline uint32_t payload(uint32_t p1) { return (p1 & 0xFFu) | ((p1 >> 12) << 8); }
+  static constexpr int NBITS = 9 - Split12L1::NBITS;
+  static constexpr uint32_t NB = 1u << NBITS;
+  __host__ __device__ static inline uint32_t bucket(uint32_t p1) { return (p1 >> 8) & (NB - 1u); }
+  __host__ __device__ static inline uint32_t payload(uint32_t p1) { return (p1 & 0xFFu) | ((p1 >> (8 + NBITS)) << 8); }
   // (bucket2, payload2) of level-1 bucket `outer` -> 24-bit id
   __host__ __device__ static inline uint32_t join(uint32_t b2, uint32_t p2, uint32_t outer) {
-    const uint32_t p1 = (p2 & 0xFFu) | (b2 << 8) | ((p2 >> 8) << 12);
+    const uint32_t p1 = (p2 & 0xFFu) | (b2 << 8) | ((p2 >> 8) << (8 + NBITS));
     return Split12L1::join(outer, p1);
   }
   __host__ __device__ static inline bool valid(uint32_t p2) { return p2 != KEY_INVALID; }
 };
 
 // W = 14 (28-bit ids) needs 2^13 buckets of 2^15 bins: three levels, bucket bits again from the middle of what is left.
-//   level 1: bucket1 = id bits [10,15), 23-bit payload1 (32-bit keys)
-//   level 2: bucket2 = payload1 bits [9,13), 19-bit payload2 (32-bit keys)
-//   level 3: bucket3 = payload2 bits [8,12), 15-bit payload3 (16-bit keys) -- the second level of W = 12
+//   level 1: bucket1 = id bits [10,14), 24-bit payload1 (32-bit keys; 16 rings of 32-bit entries per wave, like W = 12's)
+//   level 2: bucket2 = payload1 bits [9,13), 20-bit payload2 (32-bit keys)
+//   level 3: bucket3 = payload2 bits [8,13), 15-bit payload3 (16-bit keys)
 // A suppressed window (INVALID_ID) and the padding entries are all ones in every payload bit at every level: their
 // bucket bits select the last bucket, their payloads fail valid() and end as KEY_INVALID, which pass B skips.
 struct Split14L1 {
-  static constexpr uint32_t NB = 32;
-  __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> 10) & 31u; }
-  __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & 0x3FFu) | ((id >> 15) << 10); }
-  __host__ __device__ static inline uint32_t join(uint32_t b1, uint32_t p1, uint32_t /*outer*/ = 0) { return (p1 & 0x3FFu) | (b1 << 10) | ((p1 >> 10) << 15); }
-  __host__ __device__ static inline bool valid(uint32_t p1) { return p1 < (1u << 23); }
+  static constexpr int NBITS = 4;
+  static constexpr uint32_t NB = 16;
+  __host__ __device__ static inline uint32_t bucket(uint32_t id) { return (id >> 10) & 15u; }
+  __host__ __device__ static inline uint32_t payload(uint32_t id) { return (id & 0x3FFu) | ((id >> 14) << 10); }
+  __host__ __device__ static inline uint32_t join(uint32_t b1, uint32_t p1, uint32_t /*outer*/ = 0) { return (p1 & 0x3FFu) | (b1 << 10) | ((p1 >> 10) << 14); }
+  __host__ __device__ static inline bool valid(uint32_t p1) { return p1 < (1u << 24); }
 };
 struct Split14L2 {
   static constexpr int NBITS = 4;
@@ -451,16 +459,16 @@ struct Split14L2 {
   __host__ __device__ static inline uint32_t join(uint32_t b2, uint32_t p2, uint32_t outer) {
     return Split14L1::join(outer, (p2 & 0x1FFu) | (b2 << 9) | ((p2 >> 9) << 13));
   }
-  __host__ __device__ static inline bool valid(uint32_t p2) { return p2 < (1u << 19); }
+  __host__ __device__ static inline bool valid(uint32_t p2) { return p2 < (1u << 20); }
 };
 struct Split14L3 {
-  static constexpr int NBITS = 4;
-  static constexpr uint32_t NB = 16;
-  __host__ __device__ static inline uint32_t bucket(uint32_t p2) { return (p2 >> 8) & 15u; }
-  __host__ __device__ static inline uint32_t payload(uint32_t p2) { return (p2 & 0xFFu) | ((p2 >> 12) << 8); }
+  static constexpr int NBITS = 5;
+  static constexpr uint32_t NB = 32;
+  __host__ __device__ static inline uint32_t bucket(uint32_t p2) { return (p2 >> 8) & 31u; }
+  __host__ __device__ static inline uint32_t payload(uint32_t p2) { return (p2 & 0xFFu) | ((p2 >> 13) << 8); }
   // (bucket3, payload3) of the level-1 / level-2 buckets outer = b1 * 16 + b2 -> 28-bit id
   __host__ __device__ static inline uint32_t join(uint32_t b3, uint32_t p3, uint32_t outer) {
-    return Split14L2::join(outer & 15u, (p3 & 0xFFu) | (b3 << 8) | ((p3 >> 8) << 12), outer >> 4);
+    return Split14L2::join(outer & 15u, (p3 & 0xFFu) | (b3 << 8) | ((p3 >> 8) << 13), outer >> 4);
   }
   __host__ __device__ static inline bool valid(uint32_t p3) { return p3 != KEY_INVALID; }
 };
@@ -664,10 +672,14 @@ __global__ __launch_bounds__(64 * SCATTER_WPW) void count_scatter_kernel(const u
 #define PENGK_SCATTER12_WPW 3
 #endif
 constexpr int SCATTER12_WPW = PENGK_SCATTER12_WPW;
-typedef ScatterEmit<Split12L1, 5, SCATTER12_WPW, uint32_t> Scatter12Emit;
+#ifndef PENGK_SCATTER12L1_WPW
+#define PENGK_SCATTER12L1_WPW (PENGK_W12_L1_BITS == 5 ? 3 : 4)
+#endif
+constexpr int SCATTER12L1_WPW = PENGK_SCATTER12L1_WPW;  // waves per workgroup of W = 12's scan
+typedef ScatterEmit<Split12L1, Split12L1::NBITS, SCATTER12L1_WPW, uint32_t> Scatter12Emit;
 
 template <bool BOTH, bool BG>
-__global__ __launch_bounds__(64 * SCATTER12_WPW) void count_scatter12_kernel(const uint32_t* __restrict__ words32,
+__global__ __launch_bounds__(64 * SCATTER12L1_WPW) void count_scatter12_kernel(const uint32_t* __restrict__ words32,
                                                               const uint64_t* __restrict__ items, uint32_t n_items,
                                                               uint32_t* __restrict__ keys, uint32_t slice_cap,
                                                               uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
@@ -677,7 +689,7 @@ __global__ __launch_bounds__(64 * SCATTER12_WPW) void count_scatter12_kernel(con
   bg_begin<BG>();
   __syncthreads();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  Scatter12Emit e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * (uint32_t)SCATTER12_WPW + wave, 0u};
+  Scatter12Emit e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * (uint32_t)SCATTER12L1_WPW + wave, 0u};
   e.bind();
   scan_items<12, BOTH, BG>(words32, items, n_items, ltot, defer, e);
   e.drain();
@@ -691,17 +703,17 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ fill1, uint32_t n_slices1,
                                                                 uint32_t bpb1, uint16_t* __restrict__ keys2, uint32_t cap2,
                                                                 uint32_t* __restrict__ fill2, uint32_t* __restrict__ hist) {
-  ScatterEmit<Split12L2, 4>::init_lds();
+  ScatterEmit<Split12L2, Split12L2::NBITS>::init_lds();
   __syncthreads();
   const uint32_t b1 = blockIdx.x / bpb1, j = blockIdx.x % bpb1;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-  ScatterEmit<Split12L2, 4> e{keys2, cap2, fill2, hist, wave, lane, blockIdx.x * 4u + wave, b1};
+  ScatterEmit<Split12L2, Split12L2::NBITS> e{keys2, cap2, fill2, hist, wave, lane, blockIdx.x * 4u + wave, b1};
   e.bind();
   const uint32_t per = (n_slices1 + bpb1 - 1) / bpb1;
   const uint32_t first = j * per, last = min(n_slices1, first + per);
   for (uint32_t s = first + wave; s < last; s += 4) {
-    const uint32_t n = fill1[(size_t)s * 32u + b1];  // multiple of GROUP
-    const uint32_t* src = keys1 + ((size_t)s * 32u + b1) * cap1;
+    const uint32_t n = fill1[(size_t)s * Split12L1::NB + b1];  // multiple of GROUP
+    const uint32_t* src = keys1 + ((size_t)s * Split12L1::NB + b1) * cap1;
     // 256 keys per step: one 16-byte load per lane, the next step's already in flight while these four are appended
     // (one key per lane and step left the wave waiting for every line it asked for).  Padding and suppressed-window
     // entries (bits above the 19-bit payload set) need no test: their bucket bits select the last bucket and their
@@ -724,10 +736,10 @@ __global__ __launch_bounds__(256) void count_rescatter12_kernel(const uint32_t* 
 }
 
 // ---- three-level partition (W = 14) ------------------------------------------------------------------------
-typedef ScatterEmit<Split14L1, 5, SCATTER12_WPW, uint32_t> Scatter14Emit;
+typedef ScatterEmit<Split14L1, Split14L1::NBITS, SCATTER12L1_WPW, uint32_t> Scatter14Emit;
 
 template <bool BOTH, bool BG>
-__global__ __launch_bounds__(64 * SCATTER12_WPW) void count_scatter14_kernel(const uint32_t* __restrict__ words32,
+__global__ __launch_bounds__(64 * SCATTER12L1_WPW) void count_scatter14_kernel(const uint32_t* __restrict__ words32,
                                                               const uint64_t* __restrict__ items, uint32_t n_items,
                                                               uint32_t* __restrict__ keys, uint32_t slice_cap,
                                                               uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
@@ -737,7 +749,7 @@ __global__ __launch_bounds__(64 * SCATTER12_WPW) void count_scatter14_kernel(con
   bg_begin<BG>();
   __syncthreads();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  Scatter14Emit e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * (uint32_t)SCATTER12_WPW + wave, 0u};
+  Scatter14Emit e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * (uint32_t)SCATTER12L1_WPW + wave, 0u};
   e.bind();
   scan_items<14, BOTH, BG>(words32, items, n_items, ltot, defer, e);
   e.drain();
@@ -791,7 +803,7 @@ __global__ __launch_bounds__(256) void count_gather14_kernel(const uint32_t* __r
   const uint32_t np = 1u << 28;
   for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
     const uint32_t p1 = Split14L1::payload(x), p2 = Split14L2::payload(p1);
-    const uint32_t fb = (Split14L1::bucket(x) * 16u + Split14L2::bucket(p1)) * 16u + Split14L3::bucket(p2);
+    const uint32_t fb = (Split14L1::bucket(x) * Split14L2::NB + Split14L2::bucket(p1)) * Split14L3::NB + Split14L3::bucket(p2);
     const uint32_t v = temp[((size_t)fb << PAYLOAD_BITS) | Split14L3::payload(p2)];
     if (v) hist[x] += v;
   }
@@ -850,7 +862,7 @@ __global__ __launch_bounds__(256) void count_gather12_kernel(const uint32_t* __r
   const uint32_t np = 1u << 24;
   for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < np; x += gridDim.x * blockDim.x) {
     const uint32_t p1 = Split12L1::payload(x);
-    const uint32_t fb = Split12L1::bucket(x) * 16u + Split12L2::bucket(p1);
+    const uint32_t fb = Split12L1::bucket(x) * Split12L2::NB + Split12L2::bucket(p1);
     const uint32_t v = temp[((size_t)fb << PAYLOAD_BITS) | Split12L2::payload(p1)];
     if (v) hist[x] += v;
   }
@@ -1271,38 +1283,39 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
 int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items, uint64_t* d_bg) {
   const uint32_t np = 1u << 24;
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
-  constexpr uint32_t TPB1 = 64u * SCATTER12_WPW;
+  constexpr uint32_t TPB1 = 64u * SCATTER12L1_WPW;
+  constexpr uint32_t NB1 = Split12L1::NB, NB2 = Split12L2::NB;
   const uint32_t blocks_needed = (n_items + TPB1 - 1) / TPB1;
-  constexpr uint32_t lds_per_wg1 = (uint32_t)(sizeof(ScatterShared<5, SCATTER12_WPW, uint32_t>) + sizeof(BgLds) + 511u) & ~511u;
+  constexpr uint32_t lds_per_wg1 = (uint32_t)(sizeof(ScatterShared<Split12L1::NBITS, SCATTER12L1_WPW, uint32_t>) + sizeof(BgLds) + 511u) & ~511u;
   const uint32_t max_blocks = (uint32_t)ctx->num_cu * ((160u * 1024u) / lds_per_wg1);
   const uint32_t blocks1 = blocks_needed < max_blocks ? blocks_needed : max_blocks;
-  const uint32_t n_waves1 = blocks1 * (uint32_t)SCATTER12_WPW;
+  const uint32_t n_waves1 = blocks1 * (uint32_t)SCATTER12L1_WPW;
   const uint64_t windows = ctx->n_windows_hint ? ctx->n_windows_hint : ctx->n_items * (uint64_t)ctx->item_windows;
   // level-1 slices
-  uint64_t share1 = windows / (32ull * n_waves1);
+  uint64_t share1 = windows / ((uint64_t)NB1 * n_waves1);
   uint64_t cap1_64 = share1 + share1 / 2 + 256;
   if (ctx->key_cap_override) cap1_64 = ctx->key_cap_override;
   cap1_64 = (cap1_64 + 63) / 64 * 64;
   // level-2 grid: bpb1 workgroups per level-1 bucket
-  uint32_t bpb1 = ((uint32_t)ctx->num_cu * 8u + 31u) / 32u;
+  uint32_t bpb1 = ((uint32_t)ctx->num_cu * 8u + NB1 - 1u) / NB1;
   if (bpb1 > n_waves1) bpb1 = n_waves1;
   if (bpb1 < 1) bpb1 = 1;
-  const uint32_t blocks2 = 32u * bpb1;
+  const uint32_t blocks2 = NB1 * bpb1;
   const uint32_t n_waves2 = blocks2 * 4u;
-  uint64_t share2 = windows / (16ull * n_waves2);
+  uint64_t share2 = windows / ((uint64_t)NB2 * n_waves2);
   uint64_t cap2_64 = share2 + share2 / 2 + 512;
   if (ctx->key_cap_override) cap2_64 = ctx->key_cap_override;
   cap2_64 = (cap2_64 + 63) / 64 * 64;
-  if (cap1_64 * 32ull >= (1ull << 30) || cap2_64 * 16ull >= (1ull << 31)) return fail(  // 32-bit byte offsets inside a wave's slices
+  if (cap1_64 * NB1 >= (1ull << 30) || cap2_64 * NB2 >= (1ull << 31)) return fail(  // 32-bit byte offsets inside a wave's slices
       PENGK_ERR_RANGE, "shard too large for the partitioned count");
   const uint32_t cap1 = (uint32_t)cap1_64, cap2 = (uint32_t)cap2_64;
-  const size_t bytes1 = (size_t)n_waves1 * 32u * cap1 * sizeof(uint32_t);
-  const size_t bytes2 = (size_t)n_waves2 * 16u * cap2 * sizeof(uint16_t);
+  const size_t bytes1 = (size_t)n_waves1 * NB1 * cap1 * sizeof(uint32_t);
+  const size_t bytes2 = (size_t)n_waves2 * NB2 * cap2 * sizeof(uint16_t);
   int rc = ensure_scratch(ctx, &ctx->d_keys, &ctx->keys_bytes, bytes1 + bytes2);
   if (rc) return rc;
   uint32_t* keys1 = (uint32_t*)ctx->d_keys;
   uint16_t* keys2 = (uint16_t*)((char*)ctx->d_keys + bytes1);
-  const size_t fill1_words = ((size_t)n_waves1 * 32u + 63) / 64 * 64, fill2_words = ((size_t)n_waves2 * 16u + 63) / 64 * 64;
+  const size_t fill1_words = ((size_t)n_waves1 * NB1 + 63) / 64 * 64, fill2_words = ((size_t)n_waves2 * NB2 + 63) / 64 * 64;
   const size_t aux_need = (fill1_words + fill2_words + (size_t)np) * sizeof(uint32_t);
   rc = ensure_scratch(ctx, &ctx->d_count_aux, &ctx->count_aux_bytes, aux_need);
   if (rc) return rc;
@@ -1328,7 +1341,7 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   hipLaunchKernelGGL(count_rescatter12_kernel, dim3(blocks2), dim3(256), 0, ctx->stream, keys1, cap1, fill1, n_waves1, bpb1, keys2,
                      cap2, fill2, d_counts);
   PENGK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(count_hist_kernel, dim3(512), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys2, cap2, n_waves2, 16u, fill2, 1u,
+  hipLaunchKernelGGL(count_hist_kernel, dim3(512), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys2, cap2, n_waves2, NB2, fill2, 1u,
                      temp, bpb1 * 4u);
   PENGK_HIP(hipGetLastError());
   hipLaunchKernelGGL(count_gather12_kernel, dim3(4096), dim3(256), 0, ctx->stream, temp, d_counts);
@@ -1342,12 +1355,14 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
 int launch_partition14(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items, uint64_t* d_bg) {
   const size_t np = (size_t)1 << 28;
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
-  constexpr uint32_t TPB1 = 64u * SCATTER12_WPW;
+  constexpr uint32_t TPB1 = 64u * SCATTER12L1_WPW;
+  constexpr uint32_t NB1 = Split14L1::NB, NB2 = Split14L2::NB, NB3 = Split14L3::NB;
+  static_assert(NB1 * NB2 * NB3 == 8192, "2^13 LDS histograms");
   const uint32_t blocks_needed = (n_items + TPB1 - 1) / TPB1;
-  constexpr uint32_t lds_per_wg1 = (uint32_t)(sizeof(ScatterShared<5, SCATTER12_WPW, uint32_t>) + sizeof(BgLds) + 511u) & ~511u;
+  constexpr uint32_t lds_per_wg1 = (uint32_t)(sizeof(ScatterShared<Split14L1::NBITS, SCATTER12L1_WPW, uint32_t>) + sizeof(BgLds) + 511u) & ~511u;
   const uint32_t max_blocks = (uint32_t)ctx->num_cu * ((160u * 1024u) / lds_per_wg1);
   const uint32_t blocks1 = blocks_needed < max_blocks ? blocks_needed : max_blocks;
-  const uint32_t n_waves1 = blocks1 * (uint32_t)SCATTER12_WPW;
+  const uint32_t n_waves1 = blocks1 * (uint32_t)SCATTER12L1_WPW;
   const uint64_t windows = ctx->n_windows_hint ? ctx->n_windows_hint : ctx->n_items * (uint64_t)ctx->item_windows;
   auto cap_of = [&](uint64_t slices, uint64_t slack) {  // 1.5 x the uniform share of a (wave, bucket) slice, whole groups
     uint64_t c = windows / slices;
@@ -1356,28 +1371,28 @@ int launch_partition14(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
     return (c + 63) / 64 * 64;
   };
   // level 2: bpb1 workgroups per level-1 bucket; level 3: bpb2 workgroups per (level-1, level-2) bucket
-  uint32_t bpb1 = ((uint32_t)ctx->num_cu * 8u + 31u) / 32u;
+  uint32_t bpb1 = ((uint32_t)ctx->num_cu * 8u + NB1 - 1u) / NB1;
   if (bpb1 > n_waves1) bpb1 = n_waves1;
   if (bpb1 < 1) bpb1 = 1;
-  const uint32_t blocks2 = 32u * bpb1, n_waves2 = blocks2 * 4u;
-  uint32_t bpb2 = ((uint32_t)ctx->num_cu * 8u + 511u) / 512u;
+  const uint32_t blocks2 = NB1 * bpb1, n_waves2 = blocks2 * 4u;
+  uint32_t bpb2 = ((uint32_t)ctx->num_cu * 8u + NB1 * NB2 - 1u) / (NB1 * NB2);
   if (bpb2 > bpb1 * 4u) bpb2 = bpb1 * 4u;
   if (bpb2 < 1) bpb2 = 1;
-  const uint32_t blocks3 = 512u * bpb2, n_waves3 = blocks3 * 4u;
-  const uint64_t cap1_64 = cap_of(32ull * n_waves1, 256), cap2_64 = cap_of(16ull * n_waves2, 256), cap3_64 = cap_of(16ull * n_waves3, 256);
-  if (cap1_64 * 32ull >= (1ull << 30) || cap2_64 * 16ull >= (1ull << 30) || cap3_64 * 16ull >= (1ull << 31))  // 32-bit byte offsets
+  const uint32_t blocks3 = NB1 * NB2 * bpb2, n_waves3 = blocks3 * 4u;
+  const uint64_t cap1_64 = cap_of((uint64_t)NB1 * n_waves1, 256), cap2_64 = cap_of((uint64_t)NB2 * n_waves2, 256), cap3_64 = cap_of((uint64_t)NB3 * n_waves3, 256);
+  if (cap1_64 * NB1 >= (1ull << 30) || cap2_64 * NB2 >= (1ull << 30) || cap3_64 * NB3 >= (1ull << 31))  // 32-bit byte offsets
     return fail(PENGK_ERR_RANGE, "shard too large for the partitioned count");
   const uint32_t cap1 = (uint32_t)cap1_64, cap2 = (uint32_t)cap2_64, cap3 = (uint32_t)cap3_64;
-  const size_t bytes1 = (size_t)n_waves1 * 32u * cap1 * sizeof(uint32_t);
-  const size_t bytes2 = (size_t)n_waves2 * 16u * cap2 * sizeof(uint32_t);
-  const size_t bytes3 = (size_t)n_waves3 * 16u * cap3 * sizeof(uint16_t);
+  const size_t bytes1 = (size_t)n_waves1 * NB1 * cap1 * sizeof(uint32_t);
+  const size_t bytes2 = (size_t)n_waves2 * NB2 * cap2 * sizeof(uint32_t);
+  const size_t bytes3 = (size_t)n_waves3 * NB3 * cap3 * sizeof(uint16_t);
   int rc = ensure_scratch(ctx, &ctx->d_keys, &ctx->keys_bytes, bytes1 + bytes2 + bytes3);
   if (rc) return rc;
   uint32_t* keys1 = (uint32_t*)ctx->d_keys;
   uint32_t* keys2 = (uint32_t*)((char*)ctx->d_keys + bytes1);
   uint16_t* keys3 = (uint16_t*)((char*)ctx->d_keys + bytes1 + bytes2);
-  const size_t f1 = ((size_t)n_waves1 * 32u + 63) / 64 * 64, f2 = ((size_t)n_waves2 * 16u + 63) / 64 * 64,
-               f3 = ((size_t)n_waves3 * 16u + 63) / 64 * 64;
+  const size_t f1 = ((size_t)n_waves1 * NB1 + 63) / 64 * 64, f2 = ((size_t)n_waves2 * NB2 + 63) / 64 * 64,
+               f3 = ((size_t)n_waves3 * NB3 + 63) / 64 * 64;
   const size_t aux_need = (f1 + f2 + f3 + np) * sizeof(uint32_t);
   rc = ensure_scratch(ctx, &ctx->d_count_aux, &ctx->count_aux_bytes, aux_need);
   if (rc) return rc;
@@ -1401,13 +1416,13 @@ int launch_partition14(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
     rc = bg_finish_fused(ctx, blocks1, d_bg);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL((count_rescatter_kernel<Split14L2, uint32_t, 32u>), dim3(blocks2), dim3(256), 0, ctx->stream, keys1, cap1, fill1,
+  hipLaunchKernelGGL((count_rescatter_kernel<Split14L2, uint32_t, NB1>), dim3(blocks2), dim3(256), 0, ctx->stream, keys1, cap1, fill1,
                      n_waves1, 0u, bpb1, keys2, cap2, fill2, d_counts);
   PENGK_HIP(hipGetLastError());
-  hipLaunchKernelGGL((count_rescatter_kernel<Split14L3, uint16_t, 16u>), dim3(blocks3), dim3(256), 0, ctx->stream, keys2, cap2, fill2,
+  hipLaunchKernelGGL((count_rescatter_kernel<Split14L3, uint16_t, NB2>), dim3(blocks3), dim3(256), 0, ctx->stream, keys2, cap2, fill2,
                      n_waves2, bpb1 * 4u, bpb2, keys3, cap3, fill3, d_counts);
   PENGK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(count_hist_kernel, dim3(8192), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys3, cap3, n_waves3, 16u, fill3, 1u,
+  hipLaunchKernelGGL(count_hist_kernel, dim3(8192), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys3, cap3, n_waves3, NB3, fill3, 1u,
                      temp, bpb2 * 4u);
   PENGK_HIP(hipGetLastError());
   hipLaunchKernelGGL(count_gather14_kernel, dim3(8192), dim3(256), 0, ctx->stream, temp, d_counts);
