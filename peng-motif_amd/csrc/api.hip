@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <time.h>
 
 #include <new>
 
@@ -71,8 +73,20 @@ const char* pengk_error_name(int code) {
 int pengk_create(int device, pengk_ctx** out) {
   if (!out) return fail(PENGK_ERR_ARG, "pengk_create: out is NULL");
   *out = nullptr;
+  // PENGK_TIMING_CREATE=1: where the start-up of the runtime goes (stderr)
+  const bool timing = getenv("PENGK_TIMING_CREATE") != nullptr;
+  timespec t_prev;
+  clock_gettime(CLOCK_MONOTONIC, &t_prev);
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "[pengk_create] %s: %.1f ms\n", what, (t.tv_sec - t_prev.tv_sec) * 1e3 + (t.tv_nsec - t_prev.tv_nsec) * 1e-6);
+    t_prev = t;
+  };
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
+  lap("hipGetDeviceCount (runtime start)");
   if (e != hipSuccess || n <= 0)
     return fail(PENGK_ERR_DEVICE, "pengk_create: no HIP device (%s); this library has no CPU fallback",
                 e == hipSuccess ? "device count 0" : hipGetErrorString(e));
@@ -80,6 +94,7 @@ int pengk_create(int device, pengk_ctx** out) {
   PENGK_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   PENGK_HIP(hipGetDeviceProperties(&prop, device));
+  lap("hipSetDevice + properties");
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(PENGK_ERR_DEVICE, "pengk_create: device %d is %s; this build targets gfx950 only", device, prop.gcnArchName);
   pengk_ctx* c = new (std::nothrow) pengk_ctx();
@@ -92,7 +107,9 @@ int pengk_create(int device, pengk_ctx** out) {
     return hip_fail(e, "hipStreamCreate");
   }
   c->own_stream = true;
+  lap("stream");
   int rc = count_init_device();  // per-device kernel attributes (128 KiB dynamic LDS of pass B)
+  lap("kernel attributes (code object load)");
   if (rc) {
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -16,4 +16,12 @@ g++ -std=c++14 $F -Iinclude -I$H $H/shared/Alphabet.cpp $H/shared/Sequence.cpp $
 for f in tests/golden/torture.fa tests/golden/MafK_100seqs.fasta tests/golden/default_sequence_set.fa tests/golden/MafK.fasta; do
   ASAN_OPTIONS=detect_leaks=0 $T/ingest $f > /dev/null && echo "ingest ok $f"
 done
+# the chunked reader with forced chunkings, and the sharded reader (three ranks combining their shards through files)
+for c in 1 5 37; do
+  PENGK_READ_CHUNKS=$c PENGK_READ_THREADS=3 ASAN_OPTIONS=detect_leaks=0 $T/ingest tests/golden/MafK.fasta > /dev/null && echo "ingest ok MafK.fasta in $c chunks"
+done
+mkdir $T/g
+for r in 0 1 2; do ASAN_OPTIONS=detect_leaks=0 $T/ingest tests/golden/torture.fa $r 3 $T/g > $T/g/out$r 2> $T/g/err$r & done
+wait
+grep -l "views ok" $T/g/out0 $T/g/out1 $T/g/out2 | wc -l | sed "s/^/sharded ingest ok on ranks: /"
 rm -rf $T
