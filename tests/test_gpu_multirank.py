@@ -162,3 +162,18 @@ def test_streaming_pack_equals_the_staged_path(tmp_path, args):
         assert r.returncode == 0, (tag, r.stderr.decode()[-2000:])
         outs.append((r.stdout, r.stderr, meme.read_bytes(), js.read_bytes()))
     assert outs[0] == outs[1] == outs[2] == outs[3]
+
+
+@pytest.mark.parametrize("text", [b"", b">a\n>b\n", b">a\nACGT\n>b\nAC\n", b">a\nNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN\n>b\nNNNNNNNNNNNNNNNNN\n",
+                                  b">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n", b">a\nACGTTGCAAGCTAGCTAGGATCGATCGATTAGCTAGCTAGCTAGGGATCGA"],
+                         ids=["empty", "headers_only", "short", "all_n", "one_record", "no_newline"])
+def test_ranks_on_degenerate_inputs(tmp_path, text):
+    """Shards without a single record, without a single window, a file smaller than the number of ranks: three ranks
+    still end like one process does (same exit code, stdout, stderr, MEME)."""
+    fa = tmp_path / "d.fa"
+    fa.write_bytes(text)
+    rc, so, se, meme, js = run_plain([str(fa), "-w", "8"], tmp_path)
+    res = run_ranks([str(fa), "-w", "8"], 3, tmp_path)
+    assert [r[0] for r in res] == [rc] * 3, [r[2].decode()[-300:] for r in res]
+    assert (res[0][1], res[0][2], res[0][3], res[0][4]) == (so, se, meme, js)
+    assert res[1][1] == res[2][1] == b""
