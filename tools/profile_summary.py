@@ -41,7 +41,7 @@ for k in sorted(agg):
         lines.append("   %-28s mean=%.5g  n=%d" % (c, sum(v) / len(v), len(v)))
 open(os.path.join(prof, tag + "_pmc.txt"), "w").write("\n".join(lines) + "\n")
 
-stats = glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)  # newest run first
 if stats:
     shutil.copy(stats[0], os.path.join(prof, tag + "_kernel_stats.csv"))
 if os.path.exists(os.path.join(out, "bench.json")):
