@@ -549,6 +549,39 @@ struct EmTerms {
   __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)
 };
 
+// The four cells of position 0 take every fourth float: term c of cell (0, a) is x = 4 c + a.  Two ways to feed them:
+//  * a second, permuted copy of the table that the weights kernel writes beside it (term c of cell a at
+//    np + a 4^(W-1) + c): the cells then fetch like those of position W-1.  Twice the table bytes per PWM.  W <= 10,
+//    where the tables of a batch stay in the Infinity Cache and a step costs what the evaluating wave costs;
+//  * straight from the table (EmTerms0): a block is the 16384 x from 16384 b, sixty-four dword loads per lane (lane l
+//    takes x = 4 (64 k + l) + a: each wave-load walks 1 KiB of consecutive lines and keeps a quarter of it; the four
+//    cells run side by side on one XCD and share the lines in its L2).  Four times the load instructions, and at
+//    W = 10 these four cells then finish last (0.95 -> 1.17 ms for 16 PWMs, 49 -> 56 ms for 1000); but at W = 12, where
+//    every table byte comes from HBM (128 MiB per PWM with the copy), half the bytes win: 25.1 -> 21.8 ms for 16 PWMs
+//    x 10 iterations (profiles/r03_em_experiments.log).  W >= 12.
+template <int W>
+struct ScanCopy0 {
+  static constexpr bool value = W <= 10;
+};
+template <int W>
+struct EmTerms0 {
+  const float* __restrict__ w;  // the PWM's weight table (x order)
+  uint32_t a;
+  template <uint32_t NF>
+  __device__ __forceinline__ void load(uint32_t b, uint32_t /*part*/, uint32_t lane, float (&R)[64 / NF]) const {
+    static_assert(NF == 1u, "whole blocks");
+    const float* base = w + (size_t)b * (4u * seqsum::BLOCK) + 4u * lane + a;
+#pragma unroll
+    for (uint32_t k = 0; k < 64u; ++k) R[k] = base[256u * k];
+  }
+  template <uint32_t NF>
+  __device__ __forceinline__ void deposit(uint32_t /*part*/, uint32_t lane, const float (&R)[64 / NF], float* lds) const {
+#pragma unroll
+    for (uint32_t k = 0; k < 64u; ++k) lds[k * seqsum::SEG_STRIDE + lane] = R[k];
+  }
+  __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)
+};
+
 // Workgroup -> (PWM, cell): consecutive workgroups go to consecutive XCDs (8 on gfx950, each with its own 4 MiB L2), so
 // the 4 W cells of a PWM are given to ONE XCD: a PWM's weight table (4^W floats, 4 MiB at W = 10) is read once per
 // position, and the cells of positions 0 .. W-3 walk it side by side within a 256 KiB window -- from that XCD's L2
@@ -567,11 +600,25 @@ __global__ __launch_bounds__(seqsum::CHAIN_THREADS) void em_fold_scan_kernel(con
 #endif
   __shared__ __attribute__((aligned(16))) float lds[seqsum::CHAIN_LDS_FLOATS + PENGK_SCAN_LDS_PAD];
   constexpr uint32_t NP = 1u << (2 * W);
-  const float* w = wbuf + (size_t)pw * 2u * NP;
-  // position 0 reads the weights kernel's second copy, where its four cells lie like those of position W-1
-  EmTerms<W> src = (cell >> 2) == 0u ? EmTerms<W>{w + NP, (uint32_t)(W - 1), cell & 3u} : EmTerms<W>{w, cell >> 2, cell & 3u};
-  src.bind(threadIdx.x & 63u);
-  const float s = seqsum::fold_chain<EmTerms<W>, false>(src, (1u << (2 * W - 2)) / seqsum::BLOCK, lds, threadIdx.x);
+  constexpr uint32_t NBLK = (1u << (2 * W - 2)) / seqsum::BLOCK;
+  float s;
+  if constexpr (ScanCopy0<W>::value) {
+    // position 0 reads the weights kernel's second copy, where its four cells lie like those of position W-1
+    const float* w = wbuf + (size_t)pw * 2u * NP;
+    EmTerms<W> src = (cell >> 2) == 0u ? EmTerms<W>{w + NP, (uint32_t)(W - 1), cell & 3u} : EmTerms<W>{w, cell >> 2, cell & 3u};
+    src.bind(threadIdx.x & 63u);
+    s = seqsum::fold_chain<EmTerms<W>, false>(src, NBLK, lds, threadIdx.x);
+  } else {
+    const float* w = wbuf + (size_t)pw * NP;
+    if ((cell >> 2) == 0u) {  // (block-uniform)
+      const EmTerms0<W> src0{w, cell & 3u};
+      s = seqsum::fold_chain<EmTerms0<W>, false>(src0, NBLK, lds, threadIdx.x);
+    } else {
+      EmTerms<W> src{w, cell >> 2, cell & 3u};
+      src.bind(threadIdx.x & 63u);
+      s = seqsum::fold_chain<EmTerms<W>, false>(src, NBLK, lds, threadIdx.x);
+    }
+  }
   if (threadIdx.x == 0) partials[(size_t)pw * (W * 4) + cell] = (double)s;  // cell (p, a) = 4 p + a: layout of EmGeo<W, 16>
 }
 
@@ -729,7 +776,8 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   }
   constexpr bool SCAN = (1u << (2 * W - 2)) >= 4u * seqsum::BLOCK;
   const bool scan = SCAN && ctx->em_serial_scan != 0;
-  const size_t pwm_stride = scan ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)
+  constexpr bool COPY0 = SCAN && ScanCopy0<W>::value;
+  const size_t pwm_stride = (scan && COPY0) ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)
   int64_t batch = (int64_t)(budget / (pwm_stride * sizeof(float)));
   if (batch < 1) batch = 1;
   if (batch > n_pwm) batch = n_pwm;
@@ -748,7 +796,7 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
     for (int it = 0; it < max_it; ++it) {
-      if (scan)
+      if (scan && COPY0)
         hipLaunchKernelGGL((em_weights_kernel<W, true>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
                            d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
       else
