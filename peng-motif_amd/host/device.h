@@ -34,9 +34,10 @@ void start_sharded_ingest();
 void finish_ranks();
 
 // The input set of the run, packed while it is read: the FASTA reader hands every finished chunk of records to the
-// packer on its own worker threads (SequenceChunkSink, shared/SequenceSet.h), an uploader thread sends the packed chunks
-// to the device as they arrive (pengk_append_packed) -- the device context is still starting when the first ones are
-// ready -- so that packing and upload hide behind the read (src/main.cpp:18-84 does these steps one after the other).
+// packer on its own worker threads (SequenceChunkSink, shared/SequenceSet.h), which packs it straight into one pair of
+// host buffers that collect all chunks (pengk_pack_append); an uploader thread sends the stream to the device in 32 MiB
+// pieces as they fill up -- the device context is still starting when the first ones are ready -- so that packing and
+// upload hide behind the read (src/main.cpp:18-84 does these steps one after the other).
 // The packer's background counters come with it: when the input set doubles as the background set (the default,
 // src/Global.cpp:66-75) the model is built from them and no separate pass over the sequences is needed.
 struct PackedInput {
