@@ -1349,7 +1349,7 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   return PENGK_OK;
 }
 
-// W = 14: scan -> 32 buckets of 32-bit keys -> 16 each of 32-bit keys -> 16 each of 16-bit keys -> 8192 LDS histograms.
+// W = 14: scan -> 16 buckets of 32-bit keys -> 16 each of 32-bit keys -> 32 each of 16-bit keys -> 8192 LDS histograms.
 // 20 B per window through HBM (4 + 4 written and read, 2 written and read) instead of one device-scope atomic per window
 // on a 1 GiB table.
 int launch_partition14(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items, uint64_t* d_bg) {
