@@ -258,8 +258,8 @@ def test_partitioned_count_survives_a_full_bucket_region(ctx):
 
 @pytest.mark.parametrize("both", [True, False])
 def test_partitioned_count_w14_three_levels(ctx, both):
-    """W = 14 (2^28 bins = 2^13 LDS histograms): three partition levels -- scan -> 32 buckets of 32-bit keys -> 16 each
-    of 32-bit keys -> 16 each of 16-bit keys -> pass B.  Against the direct (one atomic per window) emitter, which
+    """W = 14 (2^28 bins = 2^13 LDS histograms): three partition levels -- scan -> 16 buckets of 32-bit keys -> 16 each
+    of 32-bit keys -> 32 each of 16-bit keys -> pass B.  Against the direct (one atomic per window) emitter, which
     test_count_low_complexity_long_sequences pins to the oracle at W = 14: random sequences, the many-lanes-on-one-bucket
     sets (identical sequences, a period-13 repeat, poly-T), and slices forced to overflow at every level."""
     W = 14
@@ -773,6 +773,33 @@ def test_em_serial_mode_many_pwms_in_batches(ctx, golden_dir):
         p0, it0, ch0 = po.em(W, r["counts"], r["bgp"][K], pwms[i], 1e4, 0.0, 2, mode=0, final_norm=False)
         assert bits_equal(pw[i], p0), i
         assert np.float32(change[i]).view(np.uint32) == np.float32(ch0).view(np.uint32)
+
+
+@pytest.mark.parametrize("W", [12, 14])
+def test_em_serial_scan_equals_the_fold_on_large_tables(ctx, W):
+    """W = 12 and 14: position 0's cells read every fourth float straight from the weight table (no permuted copy,
+    csrc/em.hip EmTerms0) and a cell's chain is 1024 / 16384 blocks long: the scan against the dependent-addition fold,
+    bit for bit, on device-generated tables (the oracle's 4^14 tables would take minutes)."""
+    ctx.synth(9, 0, 30000, 200, W)
+    counts, ltot, bg = ctx.count_bg(True)
+    ctx.mirror(W, counts)
+    V = ctx.bg_model(bg, 2)
+    bgprob, expected, logp, z = ctx.pattern_stats(W, True, 2, 2, V, ltot, counts)
+    bg_k = pk.DeviceArray.from_host(ctx, bgprob.to_host()[2])
+    rng = np.random.default_rng(W)
+    pwms = rng.dirichlet(np.ones(4) * 3, size=(3, W)).astype(np.float32)
+    out = {}
+    ctx.set_option("em_fast", 2)
+    try:
+        for scan in (1, 0):
+            ctx.set_option("em_serial_scan", scan)
+            out[scan] = ctx.em(W, pwms.copy(), counts, bg_k, 1e4, 0.0, 2)
+    finally:
+        ctx.set_option("em_serial_scan", 1)
+        ctx.set_option("em_fast", 1)
+    assert out[1][0].tobytes() == out[0][0].tobytes()
+    assert out[1][1].tolist() == out[0][1].tolist() and out[1][2].tobytes() == out[0][2].tobytes()
+    assert np.isfinite(out[1][0]).all() and not np.array_equal(out[1][0], pwms)
 
 
 @pytest.mark.parametrize("name", ["mafk100_w8_both", "mafk_w10_plus"])
