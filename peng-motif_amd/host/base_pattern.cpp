@@ -91,7 +91,8 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
 }
 
 BasePattern::~BasePattern() {
-  void* tables[] = {pattern_counter, pattern_bg_probabilities ? pattern_bg_probabilities[0] : nullptr, pattern_logp, pattern_zscore,
+  delete[] pattern_counter;
+  void* tables[] = {counts32, pattern_bg_probabilities ? pattern_bg_probabilities[0] : nullptr, pattern_logp, pattern_zscore,
                     expected_counts};
   for (void* t : tables)
     if (t) check(pengk_host_free(context(), t), "pengk_host_free");
@@ -107,20 +108,24 @@ float* BasePattern::fetch(const float* d_src, size_t n) {
   return (float*)h;
 }
 
+// the counts as the device holds them (32-bit): what the pipeline itself reads -- a few hundred entries of 4^W
+const uint32_t* BasePattern::host_counts32() {
+  if (!counts32) {
+    void* h = nullptr;
+    check(pengk_host_alloc(context(), number_patterns * sizeof(uint32_t), &h), "pengk_host_alloc");
+    check(pengk_memcpy_d2h(context(), h, d_counts.get(), number_patterns * sizeof(uint32_t)), "pengk_memcpy_d2h");
+    counts32 = (uint32_t*)h;
+  }
+  return counts32;
+}
+
+// the reference's size_t table (src/base_pattern.h:129), for callers of the public getter: widened on first use (at
+// W = 12 that is 134 MB written for a table nobody in the pipeline reads whole)
 size_t* BasePattern::host_counts() {
   if (!pattern_counter) {
-    const size_t NP = number_patterns;
-    void* h = nullptr;
-    check(pengk_host_alloc(context(), NP * sizeof(size_t), &h), "pengk_host_alloc");
-    // the 32-bit device counts land in the upper half and are widened in place, front to back
-    const uint32_t* c32 = (const uint32_t*)h + NP;
-    check(pengk_memcpy_d2h(context(), (void*)c32, d_counts.get(), NP * sizeof(uint32_t)), "pengk_memcpy_d2h");
-    size_t* out = (size_t*)h;
-    for (size_t i = 0; i < NP; ++i) {
-      const uint32_t c = c32[i];
-      out[i] = c;
-    }
-    pattern_counter = out;
+    const uint32_t* c32 = host_counts32();
+    pattern_counter = new size_t[number_patterns];
+    for (size_t i = 0; i < number_patterns; ++i) pattern_counter[i] = c32[i];
   }
   return pattern_counter;
 }
@@ -180,11 +185,11 @@ size_t BasePattern::baseId2IUPACId(const size_t base_pattern) {
 }
 
 float BasePattern::getExpCountFraction(const size_t pattern, const size_t pseudo_expected_pattern_counts) {
-  return (host_expected()[pattern] + (float)pseudo_expected_pattern_counts) / (float)host_counts()[pattern];
+  return (host_expected()[pattern] + (float)pseudo_expected_pattern_counts) / (float)(size_t)host_counts32()[pattern];
 }
 
 float BasePattern::getMutualInformationScore(const size_t pattern) {
-  const unsigned int observed = (unsigned int)host_counts()[pattern];
+  const unsigned int observed = (unsigned int)host_counts32()[pattern];
   return mutual_information_score((float)observed, host_expected()[pattern], (unsigned int)n_sequences);
 }
 
@@ -229,7 +234,7 @@ std::vector<size_t> BasePattern::select_base_patterns(const float zscore_thresho
       zs.resize((size_t)n);
     }
     order.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) order[i] = ranked_prefix::Entry{zs[i], ids[i]};
+    for (int64_t i = 0; i < n; ++i) order[i] = ranked_prefix::Entry(zs[i], ids[i]);
     std::sort(order.begin(), order.end(), [](const ranked_prefix::Entry& a, const ranked_prefix::Entry& b) {
       return a.z > b.z || (a.z == b.z && a.id < b.id);
     });
@@ -237,7 +242,7 @@ std::vector<size_t> BasePattern::select_base_patterns(const float zscore_thresho
   }
   // default: the ranking std::sort(order, sort_indices(pattern_zscore)) would leave (:458), down to the threshold only
   const float* pattern_zscore = on_device ? nullptr : host_zscore();
-  const size_t* pattern_counter = on_device ? nullptr : host_counts();
+  const uint32_t* pattern_counter = on_device ? nullptr : host_counts32();
   if (!on_device) n_ranked = ranked_prefix::rank(pattern_zscore, number_patterns, zscore_threshold, order);
   for (size_t r = 0; r < n_ranked; ++r) {
     const size_t x = order[r].id;
@@ -269,10 +274,12 @@ void BasePattern::print_patterns(std::vector<size_t> patterns) {
             << "\t" << std::setw(15) << "zscore" << std::endl
             << std::endl;
   std::cout << std::fixed << std::setprecision(2);
-  const size_t* pattern_counter = host_counts();
+  const uint32_t* counts = host_counts32();
   const float* expected_counts = host_expected();
   const float* pattern_zscore = host_zscore();
-  for (size_t x : patterns)
-    std::cout << std::setw(15) << toString(x) << "\t" << std::setw(15) << pattern_counter[x] << "\t" << std::setw(15)
-              << (pattern_counter[x] / expected_counts[x]) << "\t" << std::setw(15) << pattern_zscore[x] << std::endl;
+  for (size_t x : patterns) {
+    const size_t c = counts[x];  // (size_t like the reference's table: c / expected converts it to float the same way)
+    std::cout << std::setw(15) << toString(x) << "\t" << std::setw(15) << c << "\t" << std::setw(15) << (c / expected_counts[x]) << "\t"
+              << std::setw(15) << pattern_zscore[x] << std::endl;
+  }
 }

@@ -77,6 +77,7 @@ class BasePattern {
 
   // host mirrors (borrowed by the getters above, valid for the object's life), fetched on first use
   size_t* host_counts();
+  const uint32_t* host_counts32();
   float** host_bgprob();
   float* host_logp();
   float* host_zscore();
@@ -86,6 +87,7 @@ class BasePattern {
   size_t* factor;
   size_t pattern_length;
   size_t* pattern_counter = nullptr;
+  uint32_t* counts32 = nullptr;
   float** pattern_bg_probabilities = nullptr;
   float* pattern_logp = nullptr;
   float* pattern_zscore = nullptr;

@@ -305,8 +305,7 @@ void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupa
   const int cur_k = std::min((int)W - 1, k), cur_max_k = std::min((int)W - 1, max_k);
   pengk_host::Lap lap;
   BasePattern* base = new BasePattern(W, strand, cur_k, cur_max_k, sequence_set, bg_model);
-  size_t* counter = base->getPatternCounter();
-  lap("base patterns (pack, upload, count, sweep, tables to host)");
+  lap("base patterns (pack, upload, count, sweep)");
 
   auto seeds = base->select_base_patterns(params.zscore_threshold, params.count_threshold, strand == Strand::PLUS_STRAND,
                                           params.filter_neighbors);
@@ -330,10 +329,10 @@ void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupa
   for (IUPACPattern* p : unoptimized) {
     if (params.adv_pwm) {
       std::cout << "adv pwm: ";
-      p->calculate_adv_pwm(base, params.pseudo_counts, counter, bg_model->getV()[0]);
+      p->calculate_adv_pwm(base, params.pseudo_counts, nullptr, bg_model->getV()[0]);  // (aggregates on the device)
     } else {
       std::cout << "def pwm: ";
-      p->calculate_pwm(base, params.pseudo_counts, counter, bg_model->getV()[0]);
+      p->calculate_pwm(base, params.pseudo_counts, base->getPatternCounter(), bg_model->getV()[0]);
     }
     const float avg_info = calculate_pwm_info(p->get_pwm(), (unsigned)W, (unsigned)alphabet_size) / W;
     std::cout << IUPACPattern::toString(p->get_pattern(), W) << " -> " << p->get_pattern_string()

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -26,6 +27,8 @@ namespace ranked_prefix {
 struct Entry {
   float z;
   uint32_t id;
+  Entry() {}  // (no initialisation: vector::resize must not zero-fill 4^W entries that are overwritten at once)
+  Entry(float z_, uint32_t id_) : z(z_), id(id_) {}
 };
 
 // the comparator of sort_indices (src/base_pattern.h:166-172): descending z
@@ -114,9 +117,24 @@ inline void insertion(Entry* first, Entry* last) {
 inline size_t rank(const float* z, size_t n, float threshold, std::vector<Entry>& entries) {
   entries.resize(n);
   bool ordered = true;  // a NaN breaks the "right of the pivot is smaller" argument: sort everything then
-  for (size_t i = 0; i < n; ++i) {
-    entries[i] = Entry{z[i], (uint32_t)i};
-    ordered &= !(z[i] != z[i]);
+  {
+    // 4^12 entries are 134 MB: filled by several threads (the replay itself is sequential by nature)
+    unsigned nt = n < ((size_t)1 << 22) ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<char> nan(nt, 0);
+    Entry* e = entries.data();
+    auto fill = [&](unsigned t) {
+      bool any = false;
+      for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+        e[i] = Entry(z[i], (uint32_t)i);
+        any |= z[i] != z[i];
+      }
+      nan[t] = any;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(fill, t);
+    fill(0);
+    for (auto& x : th) x.join();
+    for (char c : nan) ordered &= !c;
   }
   if (!ordered || threshold != threshold) threshold = -INFINITY;
   if (n == 0) return 0;

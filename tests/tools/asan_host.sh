@@ -9,7 +9,7 @@ g++ -std=c++17 $F -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Ipeng-mo
     peng-motif_amd/csrc/pack.cpp -o $T/pack -pthread 2>/dev/null
 $T/pack
 H=peng-motif_amd/host
-g++ -std=c++14 $F -Iinclude -I$H $H/tests/ranked_prefix_test.cpp -o $T/rank 2>/dev/null
+g++ -std=c++14 $F -Iinclude -I$H $H/tests/ranked_prefix_test.cpp -o $T/rank -pthread 2>/dev/null
 $T/rank
 g++ -std=c++14 $F -Iinclude -I$H $H/shared/Alphabet.cpp $H/shared/Sequence.cpp $H/shared/SequenceSet.cpp $H/shared/BackgroundModel.cpp \
     $H/tests/host_ingest_dump.cpp -o $T/ingest -pthread 2>/dev/null
