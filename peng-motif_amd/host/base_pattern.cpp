@@ -3,9 +3,12 @@
 // (replaces src/base_pattern.cpp:17-64 and everything it calls, :231-441).
 #include "base_pattern.h"
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <new>
 #include <string>
 #include <iomanip>
 #include <iostream>
@@ -92,30 +95,54 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
 
 BasePattern::~BasePattern() {
   delete[] pattern_counter;
-  void* tables[] = {counts32, pattern_bg_probabilities ? pattern_bg_probabilities[0] : nullptr, pattern_logp, pattern_zscore,
-                    expected_counts};
-  for (void* t : tables)
-    if (t) check(pengk_host_free(context(), t), "pengk_host_free");
+  const size_t table = number_patterns * sizeof(float);
+  release_mirror(counts32, table);
+  release_mirror(pattern_bg_probabilities ? pattern_bg_probabilities[0] : nullptr, (size_t)(max_k + 1) * table);
+  release_mirror(pattern_logp, table);
+  release_mirror(pattern_zscore, table);
+  release_mirror(expected_counts, table);
   delete[] pattern_bg_probabilities;
   delete[] factor;
 }
 
-// ---- host mirrors behind the raw-pointer getters (page-locked: the copy runs at link speed) -----------------
-float* BasePattern::fetch(const float* d_src, size_t n) {
-  void* h = nullptr;
-  check(pengk_host_alloc(context(), n * sizeof(float), &h), "pengk_host_alloc");
-  check(pengk_memcpy_d2h(context(), h, d_src, n * sizeof(float)), "pengk_memcpy_d2h");
-  return (float*)h;
+// ---- host mirrors behind the raw-pointer getters ---------------------------------------------------------------
+// Small tables (W <= 10: 4 MB) are page-locked, the copy then runs at link speed.  Page-locking costs time in
+// proportion to the size, and at W >= 12 (64 MB a table) more than the faster copy returns: those mirrors are plain
+// huge-page memory.  (PENGK_MIRROR_PINNED_MAX_MB moves the limit: developer knob.)
+static size_t pinned_limit() {
+  static const size_t v = [] {
+    const char* e = std::getenv("PENGK_MIRROR_PINNED_MAX_MB");
+    return (size_t)(e ? std::atol(e) : 16) << 20;
+  }();
+  return v;
 }
+
+void* BasePattern::mirror(const void* d_src, size_t bytes) {
+  void* h = nullptr;
+  if (bytes <= pinned_limit()) {
+    check(pengk_host_alloc(context(), bytes, &h), "pengk_host_alloc");
+  } else {
+    const size_t huge = (size_t)2 << 20;
+    if (posix_memalign(&h, huge, (bytes + huge - 1) / huge * huge) != 0) throw std::bad_alloc();
+    madvise(h, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
+  }
+  check(pengk_memcpy_d2h(context(), h, d_src, bytes), "pengk_memcpy_d2h");
+  return h;
+}
+
+void BasePattern::release_mirror(void* h, size_t bytes) {
+  if (!h) return;
+  if (bytes <= pinned_limit())
+    check(pengk_host_free(context(), h), "pengk_host_free");
+  else
+    std::free(h);
+}
+
+float* BasePattern::fetch(const float* d_src, size_t n) { return (float*)mirror(d_src, n * sizeof(float)); }
 
 // the counts as the device holds them (32-bit): what the pipeline itself reads -- a few hundred entries of 4^W
 const uint32_t* BasePattern::host_counts32() {
-  if (!counts32) {
-    void* h = nullptr;
-    check(pengk_host_alloc(context(), number_patterns * sizeof(uint32_t), &h), "pengk_host_alloc");
-    check(pengk_memcpy_d2h(context(), h, d_counts.get(), number_patterns * sizeof(uint32_t)), "pengk_memcpy_d2h");
-    counts32 = (uint32_t*)h;
-  }
+  if (!counts32) counts32 = (uint32_t*)mirror(d_counts.get(), number_patterns * sizeof(uint32_t));
   return counts32;
 }
 
@@ -241,9 +268,12 @@ std::vector<size_t> BasePattern::select_base_patterns(const float zscore_thresho
     n_ranked = order.size();
   }
   // default: the ranking std::sort(order, sort_indices(pattern_zscore)) would leave (:458), down to the threshold only
+  pengk_host::Lap lap("    ");
   const float* pattern_zscore = on_device ? nullptr : host_zscore();
   const uint32_t* pattern_counter = on_device ? nullptr : host_counts32();
+  lap("z-scores and counts to the host");
   if (!on_device) n_ranked = ranked_prefix::rank(pattern_zscore, number_patterns, zscore_threshold, order);
+  lap("ranking down to the threshold");
   for (size_t r = 0; r < n_ranked; ++r) {
     const size_t x = order[r].id;
     if (!on_device) {
@@ -259,6 +289,7 @@ std::vector<size_t> BasePattern::select_base_patterns(const float zscore_thresho
         for (size_t c = 0; c < 4; ++c) seen[masked | (c << (2 * p))] = 1;
       }
   }
+  lap("walk");
   return selected;
 }
 

@@ -83,6 +83,8 @@ class BasePattern {
   float* host_zscore();
   float* host_expected();
   float* fetch(const float* d_src, size_t n);
+  void* mirror(const void* d_src, size_t bytes);
+  void release_mirror(void* h, size_t bytes);
 
   size_t* factor;
   size_t pattern_length;
