@@ -58,6 +58,8 @@ def parse_args():
                     help="pengk option em_fast inside the step: 2 = serial bit-exact (the CLI's mode), 1 = one reciprocal per weight, 0 = reference terms")
     ap.add_argument("--em-stress-pwms", type=int, default=1000,
                     help="BASELINE configs[4]: EM-only stress on this many top-count seeds of the PLUS table (split over ranks); 0 = skip")
+    ap.add_argument("--em-serial-scan", type=int, default=2,
+                    help="pengk option em_serial_scan: 2 = scan with its blocks evaluated ahead of the chain (default), 1 = scan, 0 = fold")
     ap.add_argument("--em-table-budget-mb", type=int, default=0,
                     help="pengk option em_table_budget_mb: weight tables per batch of PWMs in the serial EM mode (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,6 +157,7 @@ def main():
     ctx.set_option("count_impl", args.count_impl)
     ctx.set_option("em_fast", args.em_fast)
     ctx.set_option("em_table_budget_mb", args.em_table_budget_mb)
+    ctx.set_option("em_serial_scan", args.em_serial_scan)
 
     import ctypes as C
     rccl_ranks = 0

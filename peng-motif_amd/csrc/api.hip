@@ -127,6 +127,7 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_defer) (void)hipFree(ctx->d_defer);
   if (ctx->d_em_partials) (void)hipFree(ctx->d_em_partials);
   if (ctx->d_em_tables) (void)hipFree(ctx->d_em_tables);
+  if (ctx->d_em_blocks) (void)hipFree(ctx->d_em_blocks);
   if (ctx->d_misc) (void)hipFree(ctx->d_misc);
   if (ctx->d_keys) (void)hipFree(ctx->d_keys);
   if (ctx->d_iupac_big) (void)hipFree(ctx->d_iupac_big);
@@ -162,7 +163,8 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     return PENGK_OK;
   }
   if (strcmp(name, "em_serial_scan") == 0) {
-    if (value < 0 || value > 1) return fail(PENGK_ERR_ARG, "em_serial_scan must be 0 (dependent additions) or 1 (scan)");
+    if (value < 0 || value > 2)
+      return fail(PENGK_ERR_ARG, "em_serial_scan must be 0 (dependent additions), 1 (scan) or 2 (scan, blocks evaluated ahead)");
     ctx->em_serial_scan = (int)value;
     return PENGK_OK;
   }

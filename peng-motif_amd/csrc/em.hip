@@ -624,15 +624,14 @@ __global__ __launch_bounds__(seqsum::CHAIN_THREADS) void em_fold_scan_kernel(con
 
 // One block per PWM: sum the per-block partials in block order, then the reference's float32
 // epilogue: normalise rows (:129), change = sum |new - old| (:132-137), swap (:140-143).
+// (The work of one PWM, by a workgroup of at least 4 W threads: em_finalize_kernel, or the last of a PWM's cells in
+// em_chain_kernel.)
 template <int W, int HIMAX>
-__global__ __launch_bounds__(64) void em_finalize_kernel(float* __restrict__ pwms, int32_t* __restrict__ state,
-                                                         float* __restrict__ change_out, const double* __restrict__ partials,
-                                                         float threshold, int max_it, uint32_t* __restrict__ bad,
-                                                         const float* __restrict__ wbuf, uint32_t pwm_stride) {
+__device__ __forceinline__ void finalize_pwm(int pw, float* __restrict__ pwms, int32_t* __restrict__ state,
+                                             float* __restrict__ change_out, const double* __restrict__ partials, float threshold,
+                                             int max_it, uint32_t* __restrict__ bad, const float* __restrict__ wbuf, uint32_t pwm_stride,
+                                             float* s_new) {
   using G = EmGeo<W, HIMAX>;
-  const int pw = blockIdx.x;
-  if (state[2 * pw + 1] == 0) return;
-  __shared__ float s_new[W * 4];
   const int e = threadIdx.x;
   // serial mode with the scan: a PWM the weights kernel flagged (a negative or non-finite weight -- degenerate inputs
   // only) was left out by em_fold_scan_kernel; its cells are summed here, one thread per cell, by the plain loop
@@ -648,7 +647,8 @@ __global__ __launch_bounds__(64) void em_finalize_kernel(float* __restrict__ pwm
     } else {
       const double* src = partials + (size_t)pw * G::NB * G::CELLS + e;
       double v = 0.0;
-      for (int b = 0; b < G::NB; ++b) v += src[(size_t)b * G::CELLS];
+      // (device-scope loads: in em_chain_kernel the values were written by other workgroups of the same launch)
+      for (int b = 0; b < G::NB; ++b) v += __hip_atomic_load(src + (size_t)b * G::CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_new[e] = (float)v;
     }
   }
@@ -672,6 +672,377 @@ __global__ __launch_bounds__(64) void em_finalize_kernel(float* __restrict__ pwm
     state[2 * pw + 1] = !(change <= threshold || it >= max_it);
     change_out[pw] = change;
   }
+}
+
+template <int W, int HIMAX>
+__global__ __launch_bounds__(64) void em_finalize_kernel(float* __restrict__ pwms, int32_t* __restrict__ state,
+                                                         float* __restrict__ change_out, const double* __restrict__ partials,
+                                                         float threshold, int max_it, uint32_t* __restrict__ bad,
+                                                         const float* __restrict__ wbuf, uint32_t pwm_stride) {
+  const int pw = blockIdx.x;
+  if (state[2 * pw + 1] == 0) return;
+  __shared__ float s_new[W * 4];
+  finalize_pwm<W, HIMAX>(pw, pwms, state, change_out, partials, threshold, max_it, bad, wbuf, pwm_stride, s_new);
+}
+
+// ---- the scan with its blocks evaluated ahead of the chain (seqsum.h, "blocks ahead of their chain"; W >= 10) ----------
+// Per iteration and PWM:
+//   em_weights_span_kernel   the weights, span by span, and with them the plain sum of every block of every cell;
+//   (em_block_predict_kernel their prefix per cell = an estimate of the sum in front of each block; a block whose estimate
+//                            stays clear of a power of two from its first to its last term gets that binade -- for cells of
+//                            up to 1024 blocks the next kernel does that itself)
+//   em_span_eval_kernel      every block with a binade gets its two increments (block_increments) -- all blocks of all
+//                            cells at once, a workgroup per span of the table, instead of one after the other per cell;
+//   em_chain_kernel          one wave per cell walks the blocks: one addition per evaluated block, fold_block for the
+//                            others (the first block, where the sum climbs from zero, and the few where it crosses).
+// A span = 16384 consecutive x = 4^7: for a position p <= 6 a span holds block `span` of each of the four cells (p, a);
+// for p >= 7 it holds four consecutive blocks of the one cell (p, digit p of the span).
+template <int W>
+struct BlockGeo {
+  static_assert(W >= 8, "a span is 4^7 x");
+  static constexpr uint32_t NP = 1u << (2 * W);
+  static constexpr uint32_t SPANS = NP >> 14;
+  static constexpr uint32_t NBLK = (1u << (2 * W - 2)) / seqsum::BLOCK;  // per cell (= SPANS)
+  static constexpr uint32_t CELLS = 4u * W;
+  // cells of up to 1024 blocks: the evaluating wave adds up the cell's block sums itself; longer ones (W = 14) get their
+  // prefix from em_block_predict_kernel
+  static constexpr bool PREDICT_IN_EVAL = NBLK <= 1024u;
+  // the block of cell (p, a) that quarter q of span sp belongs to (p >= 7), and the cell's a
+  static __device__ __forceinline__ uint32_t high_block(uint32_t p, uint32_t sp, uint32_t q) {
+    const uint32_t sh = 2u * (p - 7u);
+    return 4u * (((sp >> (sh + 2u)) << sh) | (sp & ((1u << sh) - 1u))) + q;
+  }
+  static __device__ __forceinline__ uint32_t high_digit(uint32_t p, uint32_t sp) { return (sp >> (2u * (p - 7u))) & 3u; }
+};
+
+// The binade of a block from the estimates of the sum in front of it and behind it, or NO_BINADE when the two -- widened
+// by 2^-9, far more than a float32 chain of 4^13 terms drifts from the exact sum in practice -- do not share one.  A wrong
+// guess costs time, never the result (seqsum.h).
+__device__ __forceinline__ uint32_t block_binade(double before, double after) {
+  const float lo = (float)(before * (1.0 - 1.0 / 512.0)), hi = (float)(after * (1.0 + 1.0 / 512.0));
+  if (lo >= 0.0f && hi < __uint_as_float(0x7F000000u) && seqsum::binade_of(lo) == seqsum::binade_of(hi)) return seqsum::binade_of(lo);
+  return seqsum::NO_BINADE;
+}
+
+// The weights of a span, as em_weights_kernel computes them, and on the way the span's block sums.  A workgroup per span:
+// thread t = digits 0..3 of x (lane = digits 0..2: a wave stores 64 consecutive floats), 64 x per thread over digits 4..6.
+// The product over the PWM columns in the reference's order ((1*pwm[0][x0])*pwm[1][x1])... (src/peng.cpp:180-197): the
+// factors of digits 0..3 once per thread, digit 4 once per 4 x, ...; the digits above the span, equal for all its x, are
+// still multiplied last, x by x -- float products do not regroup.
+template <int W>
+__global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
+                                                              const uint32_t* __restrict__ counts, const float* __restrict__ bg,
+                                                              float saturation, float* __restrict__ wbuf, uint32_t* __restrict__ bad,
+                                                              float* __restrict__ sums) {
+  using G = BlockGeo<W>;
+  const uint32_t pw = blockIdx.y, sp = blockIdx.x;
+  if (state[2 * pw + 1] == 0) return;
+  __shared__ float s_pwm[W * 4];
+  __shared__ float part[4][28];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  if (t < W * 4) s_pwm[t] = pwms[(size_t)pw * W * 4 + t];
+  __syncthreads();
+  float* out = wbuf + (size_t)pw * G::NP + (size_t)sp * 16384u;
+  const uint32_t* cnt = counts + (size_t)sp * 16384u;
+  const float* bgs = bg + (size_t)sp * 16384u;
+  float p3 = 1.0f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) p3 = p3 * s_pwm[p * 4 + ((t >> (2 * p)) & 3u)];
+  float hi[W - 7];  // the span's own digits 7 .. W-1 (wave-uniform)
+#pragma unroll
+  for (int p = 7; p < W; ++p) hi[p - 7] = s_pwm[p * 4 + ((sp >> (2 * (p - 7))) & 3u)];
+  float f4_[4], f5_[4], f6_[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    f4_[a] = s_pwm[16 + a];
+    f5_[a] = s_pwm[20 + a];
+    f6_[a] = s_pwm[24 + a];
+  }
+  float c4[4] = {0, 0, 0, 0}, c5[4] = {0, 0, 0, 0}, c6[4] = {0, 0, 0, 0};
+  bool flagged = false;
+#pragma unroll 1
+  for (uint32_t d6 = 0; d6 < 4u; ++d6) {
+#pragma unroll
+    for (uint32_t d5 = 0; d5 < 4u; ++d5) {
+      float s5 = 0.0f;
+#pragma unroll
+      for (uint32_t d4 = 0; d4 < 4u; ++d4) {
+        const uint32_t xl = t + 256u * (d4 + 4u * d5 + 16u * d6);
+        float pr = ((p3 * f4_[d4]) * f5_[d5]) * f6_[d6];
+#pragma unroll
+        for (int p = 7; p < W; ++p) pr = pr * hi[p - 7];
+        const float odds = pr / bgs[xl];
+        const float v = ((float)cnt[xl] * saturation) / (1 + saturation / odds);  // :124-125
+        out[xl] = v;
+        flagged |= __float_as_uint(v) > 0x7F7FFFFFu;
+        c4[d4] += v;
+        s5 += v;
+      }
+      c5[d5] += s5;
+      c6[d6] += s5;
+    }
+  }
+  if (flagged) bad[pw] = 1u;  // (as em_weights_kernel: this PWM's cells are summed by the finalize kernel's plain loop)
+  const float tot = (c6[0] + c6[1]) + (c6[2] + c6[3]);
+  // per wave: whole-wave sums by digit 4, 5, 6; the total by digit 0, 1, 2 (lane bits 0-1, 2-3, 4-5); the total (digit 3)
+  auto all = [](float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+  };
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float s4 = all(c4[a]), s5 = all(c5[a]), s6 = all(c6[a]);
+    if (lane == 0) {
+      part[wave][12 + a] = s4;
+      part[wave][16 + a] = s5;
+      part[wave][20 + a] = s6;
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {  // digit d = lane bits 2 d, 2 d + 1: add over the other four bits
+    float v = tot;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1)
+      if (m != (1 << (2 * d)) && m != (2 << (2 * d))) v += __shfl_xor(v, m, 64);
+    if ((lane & ~(3u << (2 * d))) == 0u) part[wave][4 * d + (lane >> (2 * d))] = v;
+  }
+  {
+    const float v = all(tot);
+    if (lane == 0) part[wave][24] = v;
+  }
+  __syncthreads();
+  if (t < G::CELLS) {
+    const uint32_t p = t >> 2, a = t & 3u;
+    float* o = sums + (size_t)pw * G::CELLS * G::NBLK;
+    if (p <= 6u) {
+      float v;
+      if (p == 3u) v = part[a][24];  // digit 3 = the wave
+      else {
+        const uint32_t at = p <= 2u ? 4u * p + a : 4u * (p - 1u) + a;  // digits 4, 5, 6 at 12, 16, 20
+        v = (part[0][at] + part[1][at]) + (part[2][at] + part[3][at]);
+      }
+      o[(size_t)t * G::NBLK + sp] = v;
+    } else {
+      // quarter a of the span: block high_block(p, sp, a) of cell (p, digit p of the span)
+      const float v = (part[0][20 + a] + part[1][20 + a]) + (part[2][20 + a] + part[3][20 + a]);
+      o[(size_t)(4u * p + G::high_digit(p, sp)) * G::NBLK + G::high_block(p, sp, a)] = v;
+    }
+  }
+}
+
+// The prefix of a cell's block sums -> block_binade of every block (cells of more than 1024 blocks; the shorter ones are
+// predicted by em_span_eval_kernel itself).  One wave per cell; a lane takes NBLK / 64 consecutive blocks.
+template <int W>
+__global__ __launch_bounds__(64) void em_block_predict_kernel(const int32_t* __restrict__ state, const uint32_t* __restrict__ bad,
+                                                              const float* __restrict__ sums, seqsum::BlockRecord* __restrict__ rec) {
+  using G = BlockGeo<W>;
+  const uint32_t pw = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
+  if (state[2 * pw + 1] == 0 || bad[pw]) return;
+  constexpr uint32_t PER = G::NBLK / 64u;
+  static_assert(G::NBLK % 64u == 0u, "whole lanes");
+  const float* in = sums + ((size_t)pw * G::CELLS + cell) * G::NBLK + (size_t)lane * PER;
+  seqsum::BlockRecord* out = rec + ((size_t)pw * G::CELLS + cell) * G::NBLK + (size_t)lane * PER;
+  double mine = 0.0;
+  for (uint32_t i = 0; i < PER; ++i) mine += (double)in[i];
+  double before = mine;  // inclusive scan over the lanes, then exclusive
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(before, d, 64);
+    if ((int)lane >= d) before += o;
+  }
+  before -= mine;
+  for (uint32_t i = 0; i < PER; ++i) {
+    const double after = before + (double)in[i];
+    const uint32_t e = block_binade(before, after);
+    seqsum::BlockRecord r;
+    r.e = e;
+    r.d0 = 0.0f;
+    r.d1 = 0.0f;
+    r.pad = 0u;
+    out[i] = r;
+    before = after;
+  }
+}
+
+// A span in LDS, read by every cell that has a block in it: 256 rows of 64 floats; the 16-byte slot k of row R lies at
+// slot k ^ g(R), g(R) = (R ^ R >> 3 ^ R >> 4) & 15.  With that, each of the reads below -- a lane fetching four
+// consecutive terms of ITS row of 64 terms, for every way a cell's terms lie in the span -- puts the sixteen lanes that
+// ds_read_b128 serves together on sixteen different slots (checked for all positions by enumeration; the four cells of
+// position 0, every fourth float, read single dwords and pay 4-way conflicts).
+struct SpanLds {
+  static __device__ __forceinline__ uint32_t g(uint32_t R) { return (R ^ (R >> 3) ^ (R >> 4)) & 15u; }
+  static __device__ __forceinline__ uint32_t slot_of(uint32_t R, uint32_t k) { return R * 16u + (k ^ g(R)); }
+};
+
+// The terms of lane l's row (terms 64 l .. 64 l + 63 of the block) of task (p, j) of a span, from LDS.
+//   p >= 6: block = quarter j of the span (p = 6: the cell (6, j)): x_local = 4096 j + 64 l + i
+//   p = 3, 4, 5: digit p = j lies above the low six bits: whole rows, row index = l with j inserted at bit 2 p - 6
+//   p = 1, 2: rows 4 l .. 4 l + 3, a quarter of each;  p = 0: every fourth float of those rows
+template <int W>
+__device__ __forceinline__ void span_row(const float* span, uint32_t p, uint32_t j, uint32_t l, seqsum::Row& row) {
+  typedef seqsum::f4 f4;
+  const f4* s4 = reinterpret_cast<const f4*>(span);
+  if (p >= 3u) {
+    uint32_t R;
+    if (p >= 6u) {
+      R = 64u * j + l;
+    } else {
+      const uint32_t sh = 2u * p - 6u;
+      R = ((l >> sh) << (sh + 2u)) | (j << sh) | (l & ((1u << sh) - 1u));
+    }
+    const uint32_t base = R * 16u + SpanLds::g(R);
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) row.q[k] = s4[base ^ k];
+  } else if (p != 0u) {
+    // g(4 l + c) = g(4 l) ^ c: slot (s ^ g) of row 4 l + c lies at (64 l + g(4 l)) ^ (16 c + (s ^ c))
+    const uint32_t base = 64u * l + SpanLds::g(4u * l);
+    if (p == 2u) {
+#pragma unroll
+      for (uint32_t k = 0; k < 16u; ++k) row.q[k] = s4[base ^ (16u * (k >> 2) + (((k & 3u) + 4u * j) ^ (k >> 2)))];
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < 16u; ++k) row.q[k] = s4[base ^ (16u * (k >> 2) + ((4u * (k & 3u) + j) ^ (k >> 2)))];
+    }
+  } else {
+    const uint32_t base = 4u * (64u * l + SpanLds::g(4u * l)) + j;  // (in floats; j < 4 stays below the slot bits)
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) {
+      // terms 4 k .. 4 k + 3: row 4 l + (k >> 2), slots 4 (k & 3) .. + 3, component j
+      const uint32_t c = k >> 2;
+      row.q[k].x = span[base ^ (4u * (16u * c + ((4u * (k & 3u) + 0u) ^ c)))];
+      row.q[k].y = span[base ^ (4u * (16u * c + ((4u * (k & 3u) + 1u) ^ c)))];
+      row.q[k].z = span[base ^ (4u * (16u * c + ((4u * (k & 3u) + 2u) ^ c)))];
+      row.q[k].w = span[base ^ (4u * (16u * c + ((4u * (k & 3u) + 3u) ^ c)))];
+    }
+  }
+  asm volatile("" : "+v"(row.q[0]), "+v"(row.q[1]), "+v"(row.q[2]), "+v"(row.q[3]), "+v"(row.q[4]), "+v"(row.q[5]), "+v"(row.q[6]),
+               "+v"(row.q[7]), "+v"(row.q[8]), "+v"(row.q[9]), "+v"(row.q[10]), "+v"(row.q[11]), "+v"(row.q[12]), "+v"(row.q[13]),
+               "+v"(row.q[14]), "+v"(row.q[15]));
+}
+
+// One workgroup per span: the span's 64 KiB are read ONCE (not once per position) into LDS, and the eight waves share
+// the 4 W blocks that lie in it -- each block with a predicted binade gets its two increments.  As in em_fold_scan_kernel
+// a PWM's workgroups stay on one XCD.
+constexpr uint32_t SPAN_EVAL_WAVES = 8;
+template <int W>
+__global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
+                                                                            seqsum::BlockRecord* __restrict__ rec,
+                                                                            const uint32_t* __restrict__ bad, uint32_t n_pwm,
+                                                                            const float* __restrict__ sums) {
+  using G = BlockGeo<W>;
+  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+  const uint32_t pw = (lin & 7u) + 8u * (slot / G::SPANS), sp = slot % G::SPANS;
+  if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
+  __shared__ __attribute__((aligned(16))) float span[16384];
+  const uint32_t t = threadIdx.x, lane = t & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+  constexpr uint32_t TASKS = (G::CELLS + SPAN_EVAL_WAVES - 1u) / SPAN_EVAL_WAVES;  // per wave
+  seqsum::BlockRecord* cells = rec + (size_t)pw * G::CELLS * G::NBLK;
+  // task (p, j) of the span -> its cell and block
+  auto cell_of = [&](uint32_t task) { return (task >> 2) <= 6u ? task : 4u * (task >> 2) + G::high_digit(task >> 2, sp); };
+  auto block_of = [&](uint32_t task) { return (task >> 2) <= 6u ? sp : G::high_block(task >> 2, sp, task & 3u); };
+  // the binades of this wave's blocks: the estimate in front of / behind a block from the cell's block sums
+  // (block_binade), or what em_block_predict_kernel left in the record
+  __shared__ uint32_t binade[TASKS][SPAN_EVAL_WAVES];
+#pragma unroll 1
+  for (uint32_t i = 0; i < TASKS; ++i) {
+    const uint32_t task = wave + SPAN_EVAL_WAVES * i;
+    if (task < G::CELLS) {
+      const uint32_t cell = cell_of(task), b = block_of(task);
+      if constexpr (G::PREDICT_IN_EVAL) {
+        const float* cs = sums + ((size_t)pw * G::CELLS + cell) * G::NBLK;
+        float acc = 0.0f;
+#pragma unroll
+        for (uint32_t c = 0; c < G::NBLK; c += 64u) {
+          const float x = cs[c + lane];
+          acc += c + lane < b ? x : 0.0f;
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
+        if (lane == 0) binade[i][wave] = block_binade((double)acc, (double)acc + (double)cs[b]);
+      } else {
+        if (lane == 0) binade[i][wave] = cells[(size_t)cell * G::NBLK + b].e;
+      }
+    }
+  }
+  {
+    constexpr uint32_t T = 64u * SPAN_EVAL_WAVES, PER = 4096u / T;
+    const seqsum::f4* src = reinterpret_cast<const seqsum::f4*>(wbuf + (size_t)pw * G::NP + (size_t)sp * 16384u);
+    seqsum::f4* dst = reinterpret_cast<seqsum::f4*>(span);
+    seqsum::f4 v[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) v[k] = src[t + T * k];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t idx = t + T * k;
+      dst[SpanLds::slot_of(idx >> 4, idx & 15u)] = v[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t task = wave, i = 0; task < G::CELLS; task += SPAN_EVAL_WAVES, ++i) {
+    const uint32_t p = task >> 2, j = task & 3u;
+    seqsum::BlockRecord* r = cells + (size_t)cell_of(task) * G::NBLK + block_of(task);
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)binade[i][wave]);
+    if (e == seqsum::NO_BINADE) {
+      if (G::PREDICT_IN_EVAL && lane == 0) r->e = seqsum::NO_BINADE;
+      continue;
+    }
+    seqsum::Row mine;
+    span_row<W>(span, p, j, lane, mine);
+    float d0, d1;
+    const bool ok = seqsum::block_increments(mine, lane, seqsum::bases_of_binade(e), d0, d1);
+    if (lane == 0) {
+      seqsum::BlockRecord out;
+      out.e = ok ? e : seqsum::NO_BINADE;
+      out.d0 = d0;
+      out.d1 = d1;
+      out.pad = 0u;
+      *r = out;
+    }
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ state, const float* __restrict__ wbuf,
+                                                      const seqsum::BlockRecord* __restrict__ rec, double* __restrict__ partials,
+                                                      uint32_t* __restrict__ bad, uint32_t n_pwm, uint32_t* __restrict__ done,
+                                                      float* __restrict__ pwms, float* __restrict__ change_out, float threshold,
+                                                      int max_it) {
+  using G = BlockGeo<W>;
+  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+  const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
+  if (pw >= n_pwm || state[2 * pw + 1] == 0) return;
+  __shared__ __attribute__((aligned(16))) float lds[seqsum::LDS_FLOATS];
+  const uint32_t lane = threadIdx.x;
+  const seqsum::BlockRecord* r = rec + ((size_t)pw * G::CELLS + cell) * G::NBLK;
+  float s = 0.0f;
+  const float* w = wbuf + (size_t)pw * G::NP;  // (no second copy in position 0's order: few blocks are read here)
+  if (bad[pw]) {  // (a flagged PWM: summed by finalize_pwm's plain loop)
+  } else if ((cell >> 2) == 0u) {
+    const EmTerms0<W> src0{w, cell & 3u};
+    s = seqsum::walk_chain(src0, r, G::NBLK, lds, lane);
+  } else {
+    EmTerms<W> src{w, cell >> 2, cell & 3u};
+    src.bind(lane);
+    s = seqsum::walk_chain(src, r, G::NBLK, lds, lane);
+  }
+  // the PWM's last cell to arrive does what em_finalize_kernel does (one launch less per iteration)
+  // No fences (a device-scope release writes the XCD's whole L2 back): the sum is stored by a device-scope atomic, which
+  // is performed where all XCDs see it, the counter is bumped once that store has returned, and finalize_pwm reads the
+  // sums with device-scope loads.
+  uint32_t arrived = 0;
+  if (lane == 0) {
+    (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(partials + (size_t)pw * (W * 4) + cell),
+                                (unsigned long long)__double_as_longlong((double)s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    arrived = __hip_atomic_fetch_add(&done[pw], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+  if (arrived != G::CELLS - 1u) return;
+  if (lane == 0) done[pw] = 0u;
+  finalize_pwm<W, 16>((int)pw, pwms, state, change_out, partials, threshold, max_it, bad, wbuf, G::NP, lds);
 }
 
 __global__ void em_init_kernel(int n, int W, float threshold, int max_it, int32_t* __restrict__ state,
@@ -777,7 +1148,10 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   constexpr bool SCAN = (1u << (2 * W - 2)) >= 4u * seqsum::BLOCK;
   const bool scan = SCAN && ctx->em_serial_scan != 0;
   constexpr bool COPY0 = SCAN && ScanCopy0<W>::value;
-  const size_t pwm_stride = (scan && COPY0) ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)
+  // blocks evaluated ahead of the chain (W >= 10): span-major weights with block sums, no second copy of the table
+  constexpr bool AHEAD = SCAN && W >= 10;
+  const bool blocks_ahead = AHEAD && scan && ctx->em_serial_scan == 2;
+  const size_t pwm_stride = (scan && COPY0 && !blocks_ahead) ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)
   int64_t batch = (int64_t)(budget / (pwm_stride * sizeof(float)));
   if (batch < 1) batch = 1;
   if (batch > n_pwm) batch = n_pwm;
@@ -786,36 +1160,81 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   if (rc) return rc;
   // partials: one row of cells per PWM, and behind them one flag per PWM ("has a weight the scan cannot take")
   const size_t flags_at = (size_t)batch * G::CELLS * sizeof(double);
-  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, flags_at + (size_t)batch * sizeof(uint32_t));
+  // (and one counter per PWM: its cells that have arrived, em_chain_kernel)
+  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, flags_at + (size_t)2 * batch * sizeof(uint32_t));
   if (rc) return rc;
   uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_em_partials) + flags_at);
-  PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)batch * sizeof(uint32_t), ctx->stream));
+  uint32_t* done = bad + batch;
+  // blocks evaluated ahead of the chain: one float and one record per block of every cell
+  if constexpr (AHEAD) {
+    if (blocks_ahead) {
+      using B = BlockGeo<W>;
+      rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes,
+                          (size_t)batch * B::CELLS * B::NBLK * (sizeof(float) + sizeof(seqsum::BlockRecord)));
+      if (rc) return rc;
+    }
+  }
+  PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)2 * batch * sizeof(uint32_t), ctx->stream));
   // cells of at least four blocks are summed by the scan (seqsum.h; flagged PWMs by the finalize kernel's plain loop),
   // the short chains of W <= 6 by the dependent-addition fold
   const unsigned wb = (unsigned)std::min<size_t>((np / 16 + 255) / 256, 1024);  // a thread per 16 x
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
     for (int it = 0; it < max_it; ++it) {
-      if (scan && COPY0)
+      bool weights_done = false;
+      if constexpr (AHEAD) {
+        if (blocks_ahead) {
+          using B = BlockGeo<W>;
+          hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, ctx->stream,
+                             d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad,
+                             reinterpret_cast<float*>(ctx->d_em_blocks));
+          weights_done = true;
+        }
+      }
+      if (weights_done) {
+      } else if (scan && COPY0)
         hipLaunchKernelGGL((em_weights_kernel<W, true>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
                            d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
       else
         hipLaunchKernelGGL((em_weights_kernel<W, false>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
                            d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
-      bool scanned = false;
+      bool scanned = false, finalized = false;
       if constexpr (SCAN) {
         if (scan) {
-          hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(seqsum::CHAIN_THREADS), 0, ctx->stream,
-                             d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad, (uint32_t)nb);
+          bool ahead = false;
+          if constexpr (AHEAD) {
+            if (blocks_ahead) {
+              using B = BlockGeo<W>;
+              float* sums = reinterpret_cast<float*>(ctx->d_em_blocks);
+              seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
+              if (!B::PREDICT_IN_EVAL)
+                hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, ctx->stream, d_state + 2 * first,
+                                   bad, sums, rec);
+              // (PWMs in whole groups of 8, one per XCD)
+              const uint64_t wgs = (uint64_t)((nb + 7) / 8 * 8) * B::SPANS;
+              const unsigned gx = 1024u;
+              hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, ctx->stream,
+                                 d_state + 2 * first, ctx->d_em_tables, rec, bad, (uint32_t)nb, sums);
+              hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(64), 0, ctx->stream,
+                                 d_state + 2 * first, ctx->d_em_tables, rec, ctx->d_em_partials, bad, (uint32_t)nb, done,
+                                 d_pwms + (size_t)first * W * 4, d_change + first, threshold, max_it);
+              ahead = true;
+              finalized = true;
+            }
+          }
+          if (!ahead)
+            hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(seqsum::CHAIN_THREADS), 0, ctx->stream,
+                               d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad, (uint32_t)nb);
           scanned = true;
         }
       }
       if (!scanned)
         hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,
                            ctx->d_em_tables, ctx->d_em_partials, (uint32_t)pwm_stride);
-      hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
-                         d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
-                         scanned ? bad : (uint32_t*)nullptr, (const float*)ctx->d_em_tables, (uint32_t)pwm_stride);
+      if (!finalized)
+        hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
+                           d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
+                           scanned ? bad : (uint32_t*)nullptr, (const float*)ctx->d_em_tables, (uint32_t)pwm_stride);
     }
     PENGK_HIP(hipGetLastError());
   }

@@ -26,6 +26,8 @@ struct pengk_ctx {
   size_t em_partials_bytes = 0;
   float* d_em_tables = nullptr;  // K5 fast mode: count*saturation | saturation*background, 4^W floats each
   size_t em_tables_bytes = 0;
+  void* d_em_blocks = nullptr;   // K5 serial mode, blocks ahead of their chain: block sums | block records (em.hip)
+  size_t em_blocks_bytes = 0;
   void* d_misc = nullptr;  // small staging buffer
   size_t misc_bytes = 0;
   void* d_bg_partials = nullptr;  // fused K1b: per-block bins
@@ -40,7 +42,8 @@ struct pengk_ctx {
   uint64_t key_cap_override = 0; // test hook: entries per bucket region (0 = sized from the window count)
   uint64_t iupac_group_bytes = 0; // test hook: scratch budget of one group of large K4 patterns (0 = 1 GiB)
   uint64_t em_table_budget_mb = 0; // K5 serial mode: MiB of weight tables per batch of PWMs (0 = automatic)
-  int em_serial_scan = 1;       // K5 serial mode: 1 = cells summed by the parallel scan of seqsum.h, 0 = by dependent additions
+  int em_serial_scan = 2;       // K5 serial mode: cells summed by 2 = the scan of seqsum.h with its blocks evaluated ahead of
+                                // the chain (W >= 10; else as 1), 1 = the scan, block after block, 0 = dependent additions
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms
   int scatter_blocks_per_cu = 0; // tuning hook: workgroups per CU of the partitioned scan (0 = default)

@@ -145,6 +145,53 @@ __device__ __forceinline__ float lane_value(float v, int l) {  // wave-uniform
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// i0, i1 = what this lane's stretch makes of the two bases of B (the bases themselves for a lane that has nothing to add);
+// s = the sum in front of lane 0's stretch, in the binade of B.  Returns the sum behind this lane's stretch -- exact if
+// nothing left the binade up to there, >= 2^(e+1) otherwise.  An inclusive prefix composition: four DPP steps inside the
+// rows of 16 lanes, the three row boundaries with wave-uniform values; a plain prefix sum when no stretch met a tie.
+__device__ __forceinline__ float ends_behind(float i0, float i1, const Bases& B, float s, uint32_t lane) {
+  const uint32_t par = bits(s) & 1u;
+  const uint32_t rw = lane >> 4;
+  float end;
+  const float d0 = i0 - B.b0, d1 = i1 - B.b1;
+  if (__builtin_amdgcn_ballot_w64(bits(d0) != bits(d1)) == 0ull) {
+    // No row met a tie: both parities take the same increment, and the composition is a prefix SUM of increments --
+    // multiples of u below 2^24 u, so the float additions are exact (or the result is >= 2^(e+1) and gets flagged).
+    float d = d0;
+    d += row_shr<1>(0.0f, d);
+    d += row_shr<2>(0.0f, d);
+    d += row_shr<4>(0.0f, d);
+    d += row_shr<8>(0.0f, d);
+    // across the rows of 16: lane 15 of a row into every lane of the next row (rows 1 and 3), then lane 31 -- by now
+    // the total of rows 0 and 1 -- into rows 2 and 3: the wave64 scan idiom of gfx9's DPP broadcasts
+    d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+    d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+    end = s + d;
+  } else {
+    // inclusive prefix inside each row of 16 lanes: (rows l-d .. of the earlier lanes) then (this lane's)
+#define PENGK_ROW_STEP(D)                                                     \
+    {                                                                        \
+      float a0 = row_shr<D>(B.b0, i0), a1 = row_shr<D>(B.b1, i1);            \
+      compose(a0, a1, i0, i1, B);                                            \
+      i0 = a0;                                                               \
+      i1 = a1;                                                               \
+    }
+    PENGK_ROW_STEP(1) PENGK_ROW_STEP(2) PENGK_ROW_STEP(4) PENGK_ROW_STEP(8)
+#undef PENGK_ROW_STEP
+    // the rows of 16: totals at lanes 15, 31, 47; what lies in front of rows 1, 2, 3 (wave-uniform)
+    float p0 = lane_value(i0, 15), p1 = lane_value(i1, 15);  // in front of row 1
+    float q0 = p0, q1 = p1;
+    compose(q0, q1, lane_value(i0, 31), lane_value(i1, 31), B);  // in front of row 2
+    float r0 = q0, r1 = q1;
+    compose(r0, r1, lane_value(i0, 47), lane_value(i1, 47), B);  // in front of row 3
+    float f0 = rw == 1u ? p0 : rw == 2u ? q0 : rw == 3u ? r0 : B.b0;
+    float f1 = rw == 1u ? p1 : rw == 2u ? q1 : rw == 3u ? r1 : B.b1;
+    compose(f0, f1, i0, i1, B);  // rows first .. this lane's
+    end = s + (par ? f1 - B.b1 : f0 - B.b0);
+  }
+  return end;
+}
+
 // One block: `mine` holds this lane's row of 64 terms (row l = terms 64 l .. 64 l + 63 of the block); s = the sum in
 // front of the block.  Returns the sum behind it.  Wave-uniform.
 //
@@ -172,45 +219,7 @@ __device__ __forceinline__ float fold_block(const Row& mine, uint32_t lane, floa
       i0 = B.b0;
       i1 = B.b1;
     }
-    const uint32_t par = bits(s) & 1u;
-    const uint32_t rw = lane >> 4;
-    float end;  // the sum behind this lane's row, exact if nothing crossed up to there
-    const float d0 = i0 - B.b0, d1 = i1 - B.b1;
-    if (__builtin_amdgcn_ballot_w64(bits(d0) != bits(d1)) == 0ull) {
-      // No row met a tie: both parities take the same increment, and the composition is a prefix SUM of increments --
-      // multiples of u below 2^24 u, so the float additions are exact (or the result is >= 2^(e+1) and gets flagged).
-      float d = d0;
-      d += row_shr<1>(0.0f, d);
-      d += row_shr<2>(0.0f, d);
-      d += row_shr<4>(0.0f, d);
-      d += row_shr<8>(0.0f, d);
-      // across the rows of 16: lane 15 of a row into every lane of the next row (rows 1 and 3), then lane 31 -- by now
-      // the total of rows 0 and 1 -- into rows 2 and 3: the wave64 scan idiom of gfx9's DPP broadcasts
-      d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
-      d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
-      end = s + d;
-    } else {
-      // inclusive prefix inside each row of 16 lanes: (rows l-d .. of the earlier lanes) then (this lane's)
-#define PENGK_ROW_STEP(D)                                                     \
-      {                                                                        \
-        float a0 = row_shr<D>(B.b0, i0), a1 = row_shr<D>(B.b1, i1);            \
-        compose(a0, a1, i0, i1, B);                                            \
-        i0 = a0;                                                               \
-        i1 = a1;                                                               \
-      }
-      PENGK_ROW_STEP(1) PENGK_ROW_STEP(2) PENGK_ROW_STEP(4) PENGK_ROW_STEP(8)
-#undef PENGK_ROW_STEP
-      // the rows of 16: totals at lanes 15, 31, 47; what lies in front of rows 1, 2, 3 (wave-uniform)
-      float p0 = lane_value(i0, 15), p1 = lane_value(i1, 15);  // in front of row 1
-      float q0 = p0, q1 = p1;
-      compose(q0, q1, lane_value(i0, 31), lane_value(i1, 31), B);  // in front of row 2
-      float r0 = q0, r1 = q1;
-      compose(r0, r1, lane_value(i0, 47), lane_value(i1, 47), B);  // in front of row 3
-      float f0 = rw == 1u ? p0 : rw == 2u ? q0 : rw == 3u ? r0 : B.b0;
-      float f1 = rw == 1u ? p1 : rw == 2u ? q1 : rw == 3u ? r1 : B.b1;
-      compose(f0, f1, i0, i1, B);  // rows first .. this lane's
-      end = s + (par ? f1 - B.b1 : f0 - B.b0);
-    }
+    const float end = ends_behind(i0, i1, B, s, lane);  // the sum behind this lane's row, exact if nothing crossed up to there
     const unsigned long long flagged = __builtin_amdgcn_ballot_w64(bits(end) >= B.limit);
     const unsigned long long k4 = PENGK_CLOCK();
     PENGK_STAT_ADD(6, k4 - k3);
@@ -228,6 +237,162 @@ __device__ __forceinline__ float fold_block(const Row& mine, uint32_t lane, floa
     PENGK_STAT_ADD(7, PENGK_CLOCK() - k4);
     if (first == 64u) return s;
   }
+}
+
+// ---- blocks ahead of their chain ------------------------------------------------------------------------------------
+// What a block costs -- 128 additions per lane, the prefix composition -- depends on the BINADE of the sum in front of it
+// only, not on the sum: X_p = (B_p then the block's 4096 terms) for the two bases of binade e is everything the chain
+// needs from a block it passes without leaving e.  So the blocks of a chain can be evaluated all at once, each under the
+// binade a cheap estimate of the sum in front of it predicts (em.hip: block sums, their prefix), and the chain itself
+// becomes one addition per block: s <- s + (X_par - B_par), valid if s lies in e and the result stays below 2^(e+1) --
+// the same test fold_block applies to its lane 63.  A block whose binade was not predicted (the estimate too close to a
+// power of two, the sum about to cross one) or whose test fails is evaluated by fold_block as before.  Exactness never
+// rests on the estimate: it only decides which blocks take the short way.
+constexpr uint32_t NO_BINADE = 0xFFFFFFFFu;
+// exponent field of the binade of s as bases_of sees it: zero, denormals and the lowest normal binade are one
+__device__ __forceinline__ uint32_t binade_of(float s) {
+  const uint32_t e = bits(s) >> 23;
+  return e <= 1u ? 1u : e;
+}
+__device__ __forceinline__ Bases bases_of_binade(uint32_t e) {  // e = binade_of(s) of a finite s
+  Bases r;
+  r.b0 = __uint_as_float(e <= 1u ? 0u : e << 23);
+  r.b1 = __uint_as_float(e <= 1u ? 1u : (e << 23) | 1u);
+  r.limit = (e + 1u) << 23;
+  return r;
+}
+
+// The block in `mine` (row l = this lane's 64 terms) run from both bases of B: the increments D[p] = X_p - B_p, wave-
+// uniform; false if a base chain reaches the end of the binade (then nothing is known about the block).
+__device__ __forceinline__ bool block_increments(const Row& mine, uint32_t lane, const Bases& B, float& D0, float& D1) {
+  float i0 = B.b0, i1 = B.b1;
+  mine.run2(i0, i1);
+  const uint32_t rw = lane >> 4;
+  const float d0 = i0 - B.b0, d1 = i1 - B.b1;
+  float x0, x1;
+  if (__builtin_amdgcn_ballot_w64(bits(d0) != bits(d1)) == 0ull) {  // (as in fold_block: a prefix SUM of increments)
+    float d = d0;
+    d += row_shr<1>(0.0f, d);
+    d += row_shr<2>(0.0f, d);
+    d += row_shr<4>(0.0f, d);
+    d += row_shr<8>(0.0f, d);
+    d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+    d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+    x0 = B.b0 + d;
+    x1 = B.b1 + d;
+  } else {
+#define PENGK_ROW_STEP(D)                                                     \
+    {                                                                          \
+      float a0 = row_shr<D>(B.b0, i0), a1 = row_shr<D>(B.b1, i1);              \
+      compose(a0, a1, i0, i1, B);                                              \
+      i0 = a0;                                                                 \
+      i1 = a1;                                                                 \
+    }
+    PENGK_ROW_STEP(1) PENGK_ROW_STEP(2) PENGK_ROW_STEP(4) PENGK_ROW_STEP(8)
+#undef PENGK_ROW_STEP
+    float p0 = lane_value(i0, 15), p1 = lane_value(i1, 15);
+    float q0 = p0, q1 = p1;
+    compose(q0, q1, lane_value(i0, 31), lane_value(i1, 31), B);
+    float r0 = q0, r1 = q1;
+    compose(r0, r1, lane_value(i0, 47), lane_value(i1, 47), B);
+    float f0 = rw == 1u ? p0 : rw == 2u ? q0 : rw == 3u ? r0 : B.b0;
+    float f1 = rw == 1u ? p1 : rw == 2u ? q1 : rw == 3u ? r1 : B.b1;
+    compose(f0, f1, i0, i1, B);
+    x0 = f0;
+    x1 = f1;
+  }
+  x0 = lane_value(x0, 63);
+  x1 = lane_value(x1, 63);
+  D0 = x0 - B.b0;
+  D1 = x1 - B.b1;
+  // (every value above is monotone in the terms: a base chain that reached 2^(e+1) anywhere ends there or above)
+  return bits(x0) < B.limit && bits(x1) < B.limit;
+}
+
+// One evaluated block of a chain: {binade e or NO_BINADE, D[0], D[1]} (16 bytes: one load per lane and 64 blocks)
+struct BlockRecord {
+  uint32_t e;
+  float d0, d1;
+  uint32_t pad;
+};
+
+// The chain of a cell over evaluated blocks (one wave; `lds` = a row buffer of LDS_FLOATS for the blocks that need
+// fold_block).  rec[b] as block_increments left it.  n_blocks is a multiple of 64.
+template <class Source>
+__device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord* __restrict__ rec, uint32_t n_blocks, float* lds,
+                                            uint32_t lane) {
+  Stats st;
+  const unsigned long long w0 = PENGK_CLOCK();
+  float s = 0.0f;
+  float R[64];
+  uint32_t have = NO_BINADE;  // the block whose terms are in R (or on their way)
+#pragma unroll 1
+  for (uint32_t base = 0; base < n_blocks; base += 64u) {
+    const uint4 r = reinterpret_cast<const uint4*>(rec)[base + lane];
+    const unsigned long long open = __builtin_amdgcn_ballot_w64(r.x == NO_BINADE);
+    if (open && have == NO_BINADE) {
+      have = base + (uint32_t)__builtin_ctzll(open);
+      src.template load<1>(have, 0u, lane, R);
+    }
+    uint32_t j = 0;
+#pragma unroll 1
+    while (j < 64u) {
+      // the evaluated blocks from j on that share the binade of s: their increments compose like the rows of a block
+      // (ends_behind, lanes = blocks); the first one whose sum would leave the binade -- if any -- ends the run
+      const uint32_t e = binade_of(s);
+      const unsigned long long same = __builtin_amdgcn_ballot_w64(r.x == e) >> j;
+      const uint32_t len = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
+      if (len != 0u && bits(s) < INF_BITS) {
+        const Bases B = bases_of_binade(e);
+        const bool in = lane >= j && lane < j + len;
+        const float end = ends_behind(in ? B.b0 + __uint_as_float(r.y) : B.b0, in ? B.b1 + __uint_as_float(r.z) : B.b1, B, s, lane);
+        const unsigned long long flagged = __builtin_amdgcn_ballot_w64(in && bits(end) >= B.limit);
+        if (!flagged) {
+          s = lane_value(end, (int)(j + len - 1u));
+          j += len;
+          continue;
+        }
+        const uint32_t L = (uint32_t)__builtin_ctzll(flagged);
+        if (L > j) s = lane_value(end, (int)(L - 1u));
+        j = L;  // block L is where the sum leaves the binade: evaluated the long way
+      }
+      const uint32_t b = base + j;
+      const unsigned long long c0 = PENGK_CLOCK();
+      if (have != b) {
+        src.template load<1>(b, 0u, lane, R);
+        PENGK_STAT_ADD(9, 1);
+      }
+      src.template deposit<1>(0u, lane, R, lds);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      Row mine;
+      mine.read(lds + lane * SEG_STRIDE);
+      const unsigned long long rest = j < 63u ? open & ~((2ull << j) - 1ull) : 0ull;
+      have = NO_BINADE;
+      if (rest) {
+        have = base + (uint32_t)__builtin_ctzll(rest);
+        src.template load<1>(have, 0u, lane, R);
+      }
+#ifdef PENGK_SEQSUM_STATS
+      asm volatile("" : "+v"(mine.q[0]), "+v"(mine.q[15]));
+#endif
+      const unsigned long long c1 = PENGK_CLOCK();
+      PENGK_STAT_ADD(2, c1 - c0);
+      s = fold_block(mine, lane, s, st);
+#ifdef PENGK_SEQSUM_STATS
+      asm volatile("" : "+v"(s));
+#endif
+      PENGK_STAT_ADD(3, PENGK_CLOCK() - c1);
+      PENGK_STAT_ADD(0, 1);
+      ++j;
+    }
+  }
+#ifdef PENGK_SEQSUM_STATS
+  asm volatile("" : "+v"(s));
+#endif
+  PENGK_STAT_ADD(8, PENGK_CLOCK() - w0);
+  PENGK_STAT_ADD(10, 1);
+  st.flush(lane);
+  return s;
 }
 
 // The term source of a chain, for NF fetching waves: load<NF>(b, part, lane, R) fetches share `part` of block b into

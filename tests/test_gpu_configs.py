@@ -128,13 +128,14 @@ def test_config4_em_stress_1000_top_count_seeds_plus_table(ctx):
         assert np.float32(ch2[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
     # ... and the scan that evaluates those sums (csrc/seqsum.h) agrees with the dependent-addition fold on all 1000
     ctx.set_option("em_fast", 2)
-    ctx.set_option("em_serial_scan", 0)
     try:
-        dep, it3, ch3 = ctx.em(W, pw0, counts, bg_k, 1e4, 0.0, 10)
+        for scan in (0, 1):  # (`ser` above came from the default, 2: blocks evaluated ahead of their chain)
+            ctx.set_option("em_serial_scan", scan)
+            dep, it3, ch3 = ctx.em(W, pw0, counts, bg_k, 1e4, 0.0, 10)
+            assert dep.tobytes() == ser.tobytes() and it3.tolist() == it2.tolist() and ch3.tobytes() == ch2.tobytes(), scan
     finally:
-        ctx.set_option("em_serial_scan", 1)
+        ctx.set_option("em_serial_scan", 2)
         ctx.set_option("em_fast", 1)
-    assert dep.tobytes() == ser.tobytes() and it3.tolist() == it2.tolist() and ch3.tobytes() == ch2.tobytes()
     # The two modes differ by the REFERENCE's own float32 summation error, which grows with the table: 262144 serial
     # float32 additions per cell over 1.9e9 counted windows leave up to ~1e-3 absolute on a PWM entry here (SURVEY.md A.7
     # measured 1.9e-5 on a 1M-sequence set) -- the fp64-tree mode is the more accurate of the two.

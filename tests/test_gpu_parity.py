@@ -791,14 +791,15 @@ def test_em_serial_scan_equals_the_fold_on_large_tables(ctx, W):
     out = {}
     ctx.set_option("em_fast", 2)
     try:
-        for scan in (1, 0):
+        for scan in (2, 1, 0):
             ctx.set_option("em_serial_scan", scan)
             out[scan] = ctx.em(W, pwms.copy(), counts, bg_k, 1e4, 0.0, 2)
     finally:
-        ctx.set_option("em_serial_scan", 1)
+        ctx.set_option("em_serial_scan", 2)
         ctx.set_option("em_fast", 1)
-    assert out[1][0].tobytes() == out[0][0].tobytes()
-    assert out[1][1].tolist() == out[0][1].tolist() and out[1][2].tobytes() == out[0][2].tobytes()
+    for scan in (1, 2):  # 2 = the default: blocks evaluated ahead of their chain
+        assert out[scan][0].tobytes() == out[0][0].tobytes()
+        assert out[scan][1].tolist() == out[0][1].tolist() and out[scan][2].tobytes() == out[0][2].tobytes()
     assert np.isfinite(out[1][0]).all() and not np.array_equal(out[1][0], pwms)
 
 
@@ -827,14 +828,15 @@ def test_em_serial_scan_equals_the_dependent_addition_fold(ctx, golden_dir, name
     out = {}
     ctx.set_option("em_fast", 2)
     try:
-        for scan in (1, 0):
+        for scan in (2, 1, 0):
             ctx.set_option("em_serial_scan", scan)
             out[scan] = ctx.em(W, pwms, d["counts"], bg_k, 1e4, 0.0, 3)
     finally:
-        ctx.set_option("em_serial_scan", 1)
+        ctx.set_option("em_serial_scan", 2)
         ctx.set_option("em_fast", 1)
-    assert out[1][0].tobytes() == out[0][0].tobytes()
-    assert out[1][1].tolist() == out[0][1].tolist() and out[1][2].tobytes() == out[0][2].tobytes()
+    for scan in (1, 2):
+        assert out[scan][0].tobytes() == out[0][0].tobytes()
+        assert out[scan][1].tolist() == out[0][1].tolist() and out[scan][2].tobytes() == out[0][2].tobytes()
     assert np.isnan(out[1][0][8]).any() or np.isnan(out[1][0][7]).any()   # the degenerate ones did go through NaN weights
     assert np.isfinite(out[1][0][0]).all()
     # and a healthy PWM of the same batch still matches the oracle

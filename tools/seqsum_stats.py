@@ -37,3 +37,6 @@ print("per block (ticks): row read %.0f  additions %.0f/evaluation  prefix %.0f/
       (st[4] / blocks, st[5] / evals, st[6] / evals, st[7] / max(evals - blocks, 1)))
 chains = len(seeds) * 4 * W * 10
 print("per chain: %.1f blocks, %.1f extra evaluations (binade crossings)" % (blocks / chains, (evals - blocks) / chains))
+if st[10]:
+    print("chains walked over evaluated blocks: %d; per chain (ticks): total %.0f = fetch + deposit + row read %.0f + fold_block %.0f + rest; blocks not prefetched %.2f" %
+          (st[10], st[8] / st[10], st[2] / st[10], st[3] / st[10], st[9] / st[10]))
