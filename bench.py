@@ -60,6 +60,8 @@ def parse_args():
                     help="BASELINE configs[4]: EM-only stress on this many top-count seeds of the PLUS table (split over ranks); 0 = skip")
     ap.add_argument("--em-serial-scan", type=int, default=2,
                     help="pengk option em_serial_scan: 2 = scan with its blocks evaluated ahead of the chain (default), 1 = scan, 0 = fold")
+    ap.add_argument("--em-overlap", type=int, default=0,
+                    help="pengk option em_overlap: streams the serial EM's batches of PWMs take turns on (1..4; 0 = the library's default)")
     ap.add_argument("--em-table-budget-mb", type=int, default=0,
                     help="pengk option em_table_budget_mb: weight tables per batch of PWMs in the serial EM mode (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,6 +160,8 @@ def main():
     ctx.set_option("em_fast", args.em_fast)
     ctx.set_option("em_table_budget_mb", args.em_table_budget_mb)
     ctx.set_option("em_serial_scan", args.em_serial_scan)
+    if args.em_overlap:
+        ctx.set_option("em_overlap", args.em_overlap)
 
     import ctypes as C
     rccl_ranks = 0
@@ -484,11 +488,13 @@ def main():
                 # the mode the CLI ships and the bench step times: pinned to the reference's PWMs bit for bit
                 ev_s = em_stress[0] * args.em_iters * NP / (em_stress[2] * 1e-3)
                 out["roofline_em"]["parity_mode"] = {
-                    "kernel": "em_weights_kernel<%d> + em_fold_scan_kernel<%d> (K5, serial bit-exact mode, same PWMs)" % (W, W),
+                    "kernel": ("em_weights_span_kernel<%d> + em_span_eval_kernel<%d> + em_chain_kernel<%d>" % (W, W, W)
+                               if W >= 10 and args.em_serial_scan == 2 else
+                               "em_weights_kernel<%d> + em_fold_scan_kernel<%d>" % (W, W)) + " (K5, serial bit-exact mode, same PWMs)",
                     "ms": round(em_stress[2], 4), "evals_per_s": round(ev_s, 1),
                     "achieved": round(ev_s * (2 * W + 4) / 1e12, 3), "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(ev_s * (2 * W + 4) / 1e12 / FP32_VECTOR_PEAK_TF, 5),
-                    "note": "reference-parity mode: every cell's 4^(W-1) float32 additions in the reference's order (as a wave-wide scan); the throughput mode above is pinned to the fp64 oracle within 1e-5, not to the reference's own rounding"}
+                    "note": "reference-parity mode: every cell's 4^(W-1) float32 additions in the reference's order (as a wave-wide scan whose blocks are evaluated ahead of the chain, csrc/seqsum.h); the throughput mode above is pinned to the fp64 oracle within 1e-5, not to the reference's own rounding"}
         if checks:
             out["checks"] = checks
         # everything this process holds on the GPU goes before the host-side legs run: the end-to-end CLI below is its

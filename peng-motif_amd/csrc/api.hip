@@ -128,6 +128,11 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_em_partials) (void)hipFree(ctx->d_em_partials);
   if (ctx->d_em_tables) (void)hipFree(ctx->d_em_tables);
   if (ctx->d_em_blocks) (void)hipFree(ctx->d_em_blocks);
+  for (int l = 0; l < 3; ++l) {
+    if (ctx->em_streams[l]) (void)hipStreamDestroy(ctx->em_streams[l]);
+    if (ctx->em_join[l]) (void)hipEventDestroy(ctx->em_join[l]);
+  }
+  if (ctx->em_fork) (void)hipEventDestroy(ctx->em_fork);
   if (ctx->d_misc) (void)hipFree(ctx->d_misc);
   if (ctx->d_keys) (void)hipFree(ctx->d_keys);
   if (ctx->d_iupac_big) (void)hipFree(ctx->d_iupac_big);
@@ -166,6 +171,11 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     if (value < 0 || value > 2)
       return fail(PENGK_ERR_ARG, "em_serial_scan must be 0 (dependent additions), 1 (scan) or 2 (scan, blocks evaluated ahead)");
     ctx->em_serial_scan = (int)value;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "em_overlap") == 0) {
+    if (value < 1 || value > MAX_EM_LANES) return fail(PENGK_ERR_ARG, "em_overlap must be 1 .. %d streams", MAX_EM_LANES);
+    ctx->em_overlap = (int)value;
     return PENGK_OK;
   }
   if (strcmp(name, "em_table_budget_mb") == 0) {

@@ -922,8 +922,7 @@ __device__ __forceinline__ void span_row(const float* span, uint32_t p, uint32_t
 }
 
 // One workgroup per span: the span's 64 KiB are read ONCE (not once per position) into LDS, and the eight waves share
-// the 4 W blocks that lie in it -- each block with a predicted binade gets its two increments.  As in em_fold_scan_kernel
-// a PWM's workgroups stay on one XCD.
+// the 4 W blocks that lie in it -- each block with a predicted binade gets its two increments.
 constexpr uint32_t SPAN_EVAL_WAVES = 8;
 template <int W>
 __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
@@ -931,6 +930,8 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
                                                                             const uint32_t* __restrict__ bad, uint32_t n_pwm,
                                                                             const float* __restrict__ sums) {
   using G = BlockGeo<W>;
+  // (consecutive workgroups go to consecutive XCDs: a PWM's spans, and behind them its chains, stay on one -- as in
+  // em_fold_scan_kernel; 1000 PWMs x 10 iterations: 35.5 ms, with PWM = blockIdx.y 37.5)
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t pw = (lin & 7u) + 8u * (slot / G::SPANS), sp = slot % G::SPANS;
   if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
@@ -1113,6 +1114,85 @@ namespace pengk {
 namespace {
 #endif
 
+// The serial mode with the blocks evaluated ahead of their chain (em_serial_scan = 2, W >= 10), on SEVERAL streams: the
+// PWMs go round in batches, and the batches take turns on the context's stream and up to three more.  A batch's iteration
+// is weights -> block evaluation -> chains, the first two bound by arithmetic and the last by one wave per cell waiting
+// for its next block; with several batches in flight the chains of one run beside the weights and evaluations of others.
+// (PWMs are independent; every batch has its own tables, records and sums.)  `budget` = bytes of weight tables in flight.
+template <int W>
+int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
+                        const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change, size_t budget) {
+  using G = EmGeo<W, 16>;
+  using B = BlockGeo<W>;
+  const size_t np = (size_t)1 << (2 * W);
+  // lanes: option "em_overlap" (1 = one stream), as many as leave a lane at least eight PWMs (two by default: 16 PWMs x
+  // 10 iterations at W = 10 take 1.00 / 0.91 / 0.96 / 0.98 ms on 1 / 2 / 3 / 4 streams, 1000 PWMs 43 / 37.5 / 38.6 / 38.1 ms)
+  int lanes = ctx->em_overlap < 1 ? 1 : ctx->em_overlap > MAX_EM_LANES ? MAX_EM_LANES : ctx->em_overlap;
+  while (lanes > 1 && n_pwm < 8 * (int64_t)lanes) --lanes;
+  int64_t batch = (int64_t)(budget / lanes / (np * sizeof(float)));
+  if (batch < 1) batch = 1;
+  if (batch * lanes > n_pwm) batch = lanes > 1 ? ((n_pwm + lanes - 1) / lanes + 7) / 8 * 8 : n_pwm;  // (whole groups of 8 PWMs: one per XCD)
+  if (batch > 65528) batch = 65528;  // gridDim.y
+  // per lane: tables | cell sums, flags ("has a weight the scan cannot take"), arrival counters | block sums, records
+  const size_t tables_b = (size_t)batch * np * sizeof(float);
+  const size_t flags_at = (size_t)batch * G::CELLS * sizeof(double);
+  const size_t partials_b = (flags_at + (size_t)2 * batch * sizeof(uint32_t) + 255) / 256 * 256;
+  const size_t blocks_b = ((size_t)batch * B::CELLS * B::NBLK * (sizeof(float) + sizeof(seqsum::BlockRecord)) + 255) / 256 * 256;
+  int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, lanes * tables_b);
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, lanes * partials_b);
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes, lanes * blocks_b);
+  if (rc) return rc;
+  hipStream_t streams[MAX_EM_LANES];
+  streams[0] = ctx->stream;
+  for (int l = 1; l < lanes; ++l) {
+    if (!ctx->em_streams[l - 1]) PENGK_HIP(hipStreamCreateWithFlags(&ctx->em_streams[l - 1], hipStreamNonBlocking));
+    if (!ctx->em_join[l - 1]) PENGK_HIP(hipEventCreateWithFlags(&ctx->em_join[l - 1], hipEventDisableTiming));
+    streams[l] = ctx->em_streams[l - 1];
+  }
+  if (lanes > 1 && !ctx->em_fork) PENGK_HIP(hipEventCreateWithFlags(&ctx->em_fork, hipEventDisableTiming));
+  for (int l = 0; l < lanes; ++l)
+    PENGK_HIP(hipMemsetAsync(reinterpret_cast<char*>(ctx->d_em_partials) + l * partials_b + flags_at, 0, (size_t)2 * batch * sizeof(uint32_t),
+                             ctx->stream));
+  if (lanes > 1) {  // (everything enqueued so far -- the tables' producers, em_init_kernel -- comes first on all of them)
+    PENGK_HIP(hipEventRecord(ctx->em_fork, ctx->stream));
+    for (int l = 1; l < lanes; ++l) PENGK_HIP(hipStreamWaitEvent(streams[l], ctx->em_fork, 0));
+  }
+  int64_t chunk = 0;
+  for (int64_t first = 0; first < n_pwm; first += batch, ++chunk) {
+    const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
+    const int l = (int)(chunk % lanes);
+    hipStream_t st = streams[l];
+    float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_tables) + l * tables_b);
+    double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->d_em_partials) + l * partials_b);
+    uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(partials) + flags_at);
+    uint32_t* done = bad + batch;
+    float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * blocks_b);
+    seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
+    for (int it = 0; it < max_it; ++it) {
+      hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
+                         d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums);
+      if (!B::PREDICT_IN_EVAL)
+        hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec);
+      const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
+      const uint64_t wgs = (uint64_t)groups * B::SPANS;
+      const unsigned gx = 1024u;
+      hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
+                         d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums);
+      hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, d_state + 2 * first, (const float*)tables,
+                         (const seqsum::BlockRecord*)rec, partials, bad, (uint32_t)nb, done, d_pwms + (size_t)first * W * 4,
+                         d_change + first, threshold, max_it);
+    }
+    PENGK_HIP(hipGetLastError());
+  }
+  for (int l = 1; l < lanes; ++l) {
+    PENGK_HIP(hipEventRecord(ctx->em_join[l - 1], streams[l]));
+    PENGK_HIP(hipStreamWaitEvent(ctx->stream, ctx->em_join[l - 1], 0));
+  }
+  return PENGK_OK;
+}
+
 #ifndef PENGK_EM_BUDGET_GIB
 #define PENGK_EM_BUDGET_GIB 24
 #endif
@@ -1149,9 +1229,11 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   const bool scan = SCAN && ctx->em_serial_scan != 0;
   constexpr bool COPY0 = SCAN && ScanCopy0<W>::value;
   // blocks evaluated ahead of the chain (W >= 10): span-major weights with block sums, no second copy of the table
-  constexpr bool AHEAD = SCAN && W >= 10;
-  const bool blocks_ahead = AHEAD && scan && ctx->em_serial_scan == 2;
-  const size_t pwm_stride = (scan && COPY0 && !blocks_ahead) ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)
+  if constexpr (SCAN && W >= 10) {
+    if (scan && ctx->em_serial_scan == 2)
+      return launch_serial_ahead<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change, budget);
+  }
+  const size_t pwm_stride = (scan && COPY0) ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)
   int64_t batch = (int64_t)(budget / (pwm_stride * sizeof(float)));
   if (batch < 1) batch = 1;
   if (batch > n_pwm) batch = n_pwm;
@@ -1160,81 +1242,36 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   if (rc) return rc;
   // partials: one row of cells per PWM, and behind them one flag per PWM ("has a weight the scan cannot take")
   const size_t flags_at = (size_t)batch * G::CELLS * sizeof(double);
-  // (and one counter per PWM: its cells that have arrived, em_chain_kernel)
-  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, flags_at + (size_t)2 * batch * sizeof(uint32_t));
+  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, flags_at + (size_t)batch * sizeof(uint32_t));
   if (rc) return rc;
   uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_em_partials) + flags_at);
-  uint32_t* done = bad + batch;
-  // blocks evaluated ahead of the chain: one float and one record per block of every cell
-  if constexpr (AHEAD) {
-    if (blocks_ahead) {
-      using B = BlockGeo<W>;
-      rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes,
-                          (size_t)batch * B::CELLS * B::NBLK * (sizeof(float) + sizeof(seqsum::BlockRecord)));
-      if (rc) return rc;
-    }
-  }
-  PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)2 * batch * sizeof(uint32_t), ctx->stream));
+  PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)batch * sizeof(uint32_t), ctx->stream));
   // cells of at least four blocks are summed by the scan (seqsum.h; flagged PWMs by the finalize kernel's plain loop),
   // the short chains of W <= 6 by the dependent-addition fold
   const unsigned wb = (unsigned)std::min<size_t>((np / 16 + 255) / 256, 1024);  // a thread per 16 x
   for (int64_t first = 0; first < n_pwm; first += batch) {
     const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
     for (int it = 0; it < max_it; ++it) {
-      bool weights_done = false;
-      if constexpr (AHEAD) {
-        if (blocks_ahead) {
-          using B = BlockGeo<W>;
-          hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, ctx->stream,
-                             d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad,
-                             reinterpret_cast<float*>(ctx->d_em_blocks));
-          weights_done = true;
-        }
-      }
-      if (weights_done) {
-      } else if (scan && COPY0)
+      if (scan && COPY0)
         hipLaunchKernelGGL((em_weights_kernel<W, true>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
                            d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
       else
         hipLaunchKernelGGL((em_weights_kernel<W, false>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
                            d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
-      bool scanned = false, finalized = false;
+      bool scanned = false;
       if constexpr (SCAN) {
         if (scan) {
-          bool ahead = false;
-          if constexpr (AHEAD) {
-            if (blocks_ahead) {
-              using B = BlockGeo<W>;
-              float* sums = reinterpret_cast<float*>(ctx->d_em_blocks);
-              seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
-              if (!B::PREDICT_IN_EVAL)
-                hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, ctx->stream, d_state + 2 * first,
-                                   bad, sums, rec);
-              // (PWMs in whole groups of 8, one per XCD)
-              const uint64_t wgs = (uint64_t)((nb + 7) / 8 * 8) * B::SPANS;
-              const unsigned gx = 1024u;
-              hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, ctx->stream,
-                                 d_state + 2 * first, ctx->d_em_tables, rec, bad, (uint32_t)nb, sums);
-              hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(64), 0, ctx->stream,
-                                 d_state + 2 * first, ctx->d_em_tables, rec, ctx->d_em_partials, bad, (uint32_t)nb, done,
-                                 d_pwms + (size_t)first * W * 4, d_change + first, threshold, max_it);
-              ahead = true;
-              finalized = true;
-            }
-          }
-          if (!ahead)
-            hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(seqsum::CHAIN_THREADS), 0, ctx->stream,
-                               d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad, (uint32_t)nb);
+          hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(seqsum::CHAIN_THREADS), 0, ctx->stream,
+                             d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad, (uint32_t)nb);
           scanned = true;
         }
       }
       if (!scanned)
         hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,
                            ctx->d_em_tables, ctx->d_em_partials, (uint32_t)pwm_stride);
-      if (!finalized)
-        hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
-                           d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
-                           scanned ? bad : (uint32_t*)nullptr, (const float*)ctx->d_em_tables, (uint32_t)pwm_stride);
+      hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
+                         d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
+                         scanned ? bad : (uint32_t*)nullptr, (const float*)ctx->d_em_tables, (uint32_t)pwm_stride);
     }
     PENGK_HIP(hipGetLastError());
   }

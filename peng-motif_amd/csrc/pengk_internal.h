@@ -28,6 +28,8 @@ struct pengk_ctx {
   size_t em_tables_bytes = 0;
   void* d_em_blocks = nullptr;   // K5 serial mode, blocks ahead of their chain: block sums | block records (em.hip)
   size_t em_blocks_bytes = 0;
+  hipStream_t em_streams[3] = {nullptr, nullptr, nullptr};  // K5 serial mode: the streams beside `stream` that batches of PWMs take turns on
+  hipEvent_t em_fork = nullptr, em_join[3] = {nullptr, nullptr, nullptr};
   void* d_misc = nullptr;  // small staging buffer
   size_t misc_bytes = 0;
   void* d_bg_partials = nullptr;  // fused K1b: per-block bins
@@ -42,6 +44,7 @@ struct pengk_ctx {
   uint64_t key_cap_override = 0; // test hook: entries per bucket region (0 = sized from the window count)
   uint64_t iupac_group_bytes = 0; // test hook: scratch budget of one group of large K4 patterns (0 = 1 GiB)
   uint64_t em_table_budget_mb = 0; // K5 serial mode: MiB of weight tables per batch of PWMs (0 = automatic)
+  int em_overlap = 2;           // K5 serial mode, em_serial_scan = 2: streams that batches of PWMs take turns on (1 .. MAX_EM_LANES)
   int em_serial_scan = 2;       // K5 serial mode: cells summed by 2 = the scan of seqsum.h with its blocks evaluated ahead of
                                 // the chain (W >= 10; else as 1), 1 = the scan, block after block, 0 = dependent additions
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
@@ -74,6 +77,8 @@ void comm_release(pengk_ctx* ctx);  // destroys the RCCL communicator, if any
 inline bool valid_w(int W) { return W >= PENGK_MIN_W && W <= PENGK_MAX_W && (W % 2) == 0; }
 
 // item record fields
+constexpr int MAX_EM_LANES = 4;
+
 constexpr uint64_t ITEM_WS_MASK = (1ull << 40) - 1;
 constexpr int ITEM_NW_SHIFT = 40;
 constexpr uint64_t ITEM_NW_MASK = 0xFFFF;

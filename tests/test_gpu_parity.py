@@ -866,8 +866,9 @@ def test_seed_candidates_on_device(ctx, golden_dir, name):
     assert np.array_equal(zs[: n.value], r["z"][ids[: n.value]])
     # a too small buffer reports the full count
     n2 = C.c_int64()
-    pk._check(pk.lib().pengk_seed_candidates(ctx.h, W, pk._ptr(d["z"]), pk._ptr(d["counts"]), zthr, cthr, ids.ctypes.data,
-                                             zs.ctypes.data, 4, C.byref(n2)))
+    ids4, zs4 = np.zeros(4, np.uint32), np.zeros(4, np.float32)  # (own buffers: the device hands candidates out in any order)
+    pk._check(pk.lib().pengk_seed_candidates(ctx.h, W, pk._ptr(d["z"]), pk._ptr(d["counts"]), zthr, cthr, ids4.ctypes.data,
+                                             zs4.ctypes.data, 4, C.byref(n2)))
     assert n2.value == n.value
     if not both:
         # single strand: exact z ties between DIFFERENT k-mers that are Hamming neighbours of each other are broken by
