@@ -547,6 +547,29 @@ struct EmTerms {
     }
   }
   __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)
+
+  // Block b straight into LDS (global_load_lds: no registers, so several blocks can be on their way and the wait for one
+  // of them is a counted s_waitcnt; seqsum.h, walk_chain).  The k-th of the sixteen loads writes 1 KiB of LDS in lane
+  // order: four rows of 64 terms, lane l the 16-byte slot l & 15 of row 4 k + (l >> 4) -- and which four terms lie there
+  // is the reader's choice: slot c of row r holds the terms 4 (c ^ (r & 15)) .. + 3 of the row, so that the lanes that
+  // read one slot number of their own rows together hit sixteen different slots (seqsum::Row::read_staged).
+  static constexpr uint32_t STAGE_LOADS = 16;
+  uint32_t gs[16];
+  __device__ __forceinline__ void bind_stage(uint32_t lane) {
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) {
+      const uint32_t r = 4u * k + (lane >> 4);
+      gs[k] = 4u * x_of(64u * r + 4u * ((lane & 15u) ^ (r & 15u)));
+    }
+  }
+  __device__ __forceinline__ void stage(uint32_t b, uint32_t /*lane*/, seqsum::lds_float* buf) const {
+    const uint32_t F = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x_of(b * seqsum::BLOCK) - (a << (2u * p))));
+    const char* base = reinterpret_cast<const char*>(w + F);
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + gs[k]),
+                                       (__attribute__((address_space(3))) void*)(buf + 256u * k), 16, 0, 0);
+  }
 };
 
 // The four cells of position 0 take every fourth float: term c of cell (0, a) is x = 4 c + a.  Two ways to feed them:
@@ -580,6 +603,19 @@ struct EmTerms0 {
     for (uint32_t k = 0; k < 64u; ++k) lds[k * seqsum::SEG_STRIDE + lane] = R[k];
   }
   __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)
+
+  // (as EmTerms::stage, with dword loads: the k-th of 64 writes row k, lane l the term whose place is l)
+  static constexpr uint32_t STAGE_LOADS = 64;
+  __device__ __forceinline__ void bind_stage(uint32_t) {}
+  __device__ __forceinline__ void stage(uint32_t b, uint32_t lane, seqsum::lds_float* buf) const {
+    const float* base = w + (size_t)b * (4u * seqsum::BLOCK) + a;
+#pragma unroll
+    for (uint32_t k = 0; k < 64u; ++k) {
+      const uint32_t term = ((((lane >> 2) ^ (k & 15u)) << 2) | (lane & 3u));  // slot (l >> 2) of row k holds slot ^ (k & 15)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + 4u * (64u * k + term)),
+                                       (__attribute__((address_space(3))) void*)(buf + 64u * k), 4, 0, 0);
+    }
+  }
 };
 
 // Workgroup -> (PWM, cell): consecutive workgroups go to consecutive XCDs (8 on gfx950, each with its own 4 MiB L2), so
@@ -1015,19 +1051,20 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
   if (pw >= n_pwm || state[2 * pw + 1] == 0) return;
-  __shared__ __attribute__((aligned(16))) float lds[seqsum::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[seqsum::WALK_LDS_FLOATS];
   const uint32_t lane = threadIdx.x;
   const seqsum::BlockRecord* r = rec + ((size_t)pw * G::CELLS + cell) * G::NBLK;
   float s = 0.0f;
   const float* w = wbuf + (size_t)pw * G::NP;  // (no second copy in position 0's order: few blocks are read here)
   if (bad[pw]) {  // (a flagged PWM: summed by finalize_pwm's plain loop)
   } else if ((cell >> 2) == 0u) {
-    const EmTerms0<W> src0{w, cell & 3u};
-    s = seqsum::walk_chain(src0, r, G::NBLK, lds, lane);
+    EmTerms0<W> src0{w, cell & 3u};
+    src0.bind_stage(lane);
+    s = seqsum::walk_chain(src0, r, G::NBLK, (seqsum::lds_float*)lds, lane);
   } else {
     EmTerms<W> src{w, cell >> 2, cell & 3u};
-    src.bind(lane);
-    s = seqsum::walk_chain(src, r, G::NBLK, lds, lane);
+    src.bind_stage(lane);
+    s = seqsum::walk_chain(src, r, G::NBLK, (seqsum::lds_float*)lds, lane);
   }
   // the PWM's last cell to arrive does what em_finalize_kernel does (one launch less per iteration)
   // No fences (a device-scope release writes the XCD's whole L2 back): the sum is stored by a device-scope atomic, which
@@ -1117,7 +1154,10 @@ namespace {
 // The serial mode with the blocks evaluated ahead of their chain (em_serial_scan = 2, W >= 10), on SEVERAL streams: the
 // PWMs go round in batches, and the batches take turns on the context's stream and up to three more.  A batch's iteration
 // is weights -> block evaluation -> chains, the first two bound by arithmetic and the last by one wave per cell waiting
-// for its next block; with several batches in flight the chains of one run beside the weights and evaluations of others.
+// for its next block; with several batches in flight the waits of one are filled by the others.  (Left to themselves the
+// lanes fall into step -- chains beside chains, weights beside weights: 0.89 ms for 16 PWMs x 10 iterations at W = 10
+// against 0.96 on one stream.  Starting the second lane when the first one's chains start, so that chains run beside
+// weights, was measured: 0.99 ms -- a chain's 32 KiB of LDS per wave halve the evaluation kernel's workgroups per CU.)
 // (PWMs are independent; every batch has its own tables, records and sums.)  `budget` = bytes of weight tables in flight.
 template <int W>
 int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,

@@ -40,6 +40,8 @@ constexpr uint32_t LDS_FLOATS = 64 * SEG_STRIDE;
 constexpr uint32_t INF_BITS = 0x7F800000u;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_float;  // (LDS as LDS: global_load_lds takes no generic pointer)
+typedef __attribute__((address_space(3))) f4 lds_f4;
 
 #ifdef PENGK_SEQSUM_STATS  // developer build: where a chain's time goes (tools/seqsum_stats.py)
 __device__ unsigned long long g_stats[12];
@@ -97,6 +99,14 @@ struct Row {
 #pragma unroll
     for (uint32_t j = 0; j < SEG / 4u; ++j) q[j] = src[j];
     static_assert(SEG == 64u, "sixteen quads");
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
+                 "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]));
+  }
+  // a row of a block that Source::stage put into LDS: 256-byte rows, slot c of row l at c ^ (l & 15)
+  __device__ __forceinline__ void read_staged(const lds_float* buf, uint32_t l) {
+    const lds_f4* src = (const lds_f4*)buf + 16u * l;
+#pragma unroll
+    for (uint32_t j = 0; j < SEG / 4u; ++j) q[j] = src[j ^ (l & 15u)];
     asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
                  "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]));
   }
@@ -316,23 +326,47 @@ struct BlockRecord {
   uint32_t pad;
 };
 
-// The chain of a cell over evaluated blocks (one wave; `lds` = a row buffer of LDS_FLOATS for the blocks that need
-// fold_block).  rec[b] as block_increments left it.  n_blocks is a multiple of 64.
+// The chain of a cell over evaluated blocks (one wave).  rec[b] as block_increments left it; n_blocks is a multiple of 64.
+// The blocks without a binade come from the table, through LDS: Source::stage(b, lane, buf) asks for block b with loads
+// that write LDS directly (16 KiB, rows of 256 bytes, Row::read_staged).  No register waits for them, so TWO blocks are
+// on their way at any time and the wait for the earlier one is `s_waitcnt vmcnt(loads of the later one)`: walking the
+// evaluated blocks between two fetched ones, and fold_block on one, take less time than memory does (~3 us for a
+// block another kernel wrote), and with loads into registers -- where the compiler places the waits, vmcnt(0) whenever
+// it cannot count -- the chain stood waiting at every fetched block.  lds = two buffers of BLOCK floats.
+constexpr uint32_t WALK_LDS_FLOATS = 2u * BLOCK;
+template <uint32_t N>
+__device__ __forceinline__ void wait_loads_but() {  // until at most N of this wave's loads are outstanding
+  static_assert(N == 0u || N == 16u, "the counts walk_chain needs");
+  if (N == 0u)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
 template <class Source>
-__device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord* __restrict__ rec, uint32_t n_blocks, float* lds,
+__device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord* __restrict__ rec, uint32_t n_blocks, lds_float* lds,
                                             uint32_t lane) {
   Stats st;
   const unsigned long long w0 = PENGK_CLOCK();
   float s = 0.0f;
-  float R[64];
-  uint32_t have = NO_BINADE;  // the block whose terms are in R (or on their way)
+  lds_float* bufa = lds;
+  lds_float* bufb = lds + BLOCK;
+  uint32_t ha = NO_BINADE, hb = NO_BINADE;  // the blocks in bufa / bufb (or on their way)
+  bool a_first = true;                      // which of the two was asked for first
 #pragma unroll 1
   for (uint32_t base = 0; base < n_blocks; base += 64u) {
     const uint4 r = reinterpret_cast<const uint4*>(rec)[base + lane];
     const unsigned long long open = __builtin_amdgcn_ballot_w64(r.x == NO_BINADE);
-    if (open && have == NO_BINADE) {
-      have = base + (uint32_t)__builtin_ctzll(open);
-      src.template load<1>(have, 0u, lane, R);
+    auto open_after = [&](uint32_t b) {  // the next block of this chunk without a binade behind block b, or NO_BINADE
+      const uint32_t j = b - base;
+      const unsigned long long rest = j < 63u ? open & ~((2ull << j) - 1ull) : 0ull;
+      return rest ? base + (uint32_t)__builtin_ctzll(rest) : NO_BINADE;
+    };
+    if (open) {  // (nothing is in flight across chunks)
+      ha = base + (uint32_t)__builtin_ctzll(open);
+      src.stage(ha, lane, bufa);
+      hb = open_after(ha);
+      if (hb != NO_BINADE) src.stage(hb, lane, bufb);
+      a_first = true;
     }
     uint32_t j = 0;
 #pragma unroll 1
@@ -358,23 +392,32 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
       }
       const uint32_t b = base + j;
       const unsigned long long c0 = PENGK_CLOCK();
-      if (have != b) {
-        src.template load<1>(b, 0u, lane, R);
-        PENGK_STAT_ADD(9, 1);
-      }
-      src.template deposit<1>(0u, lane, R, lds);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       Row mine;
-      mine.read(lds + lane * SEG_STRIDE);
-      const unsigned long long rest = j < 63u ? open & ~((2ull << j) - 1ull) : 0ull;
-      have = NO_BINADE;
-      if (rest) {
-        have = base + (uint32_t)__builtin_ctzll(rest);
-        src.template load<1>(have, 0u, lane, R);
+      // buf1 / h1 = the block asked for first.  Block b is that one -- then its buffer is free once the rows are in
+      // registers, the block behind the later one is asked for, and the later one becomes the first -- or b is a block
+      // whose binade did not hold: fetched now, through buf1, whose own block is asked for again.
+#define PENGK_TAKE(buf1, h1, h2)                                                          \
+      {                                                                                   \
+        const bool ahead = h1 == b;                                                       \
+        if (!ahead) {                                                                     \
+          src.stage(b, lane, buf1);                                                       \
+          wait_loads_but<0u>();                                                           \
+          PENGK_STAT_ADD(9, 1);                                                           \
+        } else if (h2 != NO_BINADE && Source::STAGE_LOADS == 16u) {                       \
+          wait_loads_but<16u>();                                                          \
+        } else {                                                                          \
+          wait_loads_but<0u>();                                                           \
+        }                                                                                 \
+        mine.read_staged(buf1, lane);                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+        if (ahead) {                                                                      \
+          h1 = open_after(h2 != NO_BINADE ? h2 : b);                                      \
+          a_first = !a_first;                                                             \
+        }                                                                                 \
+        if (h1 != NO_BINADE) src.stage(h1, lane, buf1);                                   \
       }
-#ifdef PENGK_SEQSUM_STATS
-      asm volatile("" : "+v"(mine.q[0]), "+v"(mine.q[15]));
-#endif
+      if (a_first) PENGK_TAKE(bufa, ha, hb) else PENGK_TAKE(bufb, hb, ha)
+#undef PENGK_TAKE
       const unsigned long long c1 = PENGK_CLOCK();
       PENGK_STAT_ADD(2, c1 - c0);
       s = fold_block(mine, lane, s, st);
@@ -392,6 +435,7 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
   PENGK_STAT_ADD(8, PENGK_CLOCK() - w0);
   PENGK_STAT_ADD(10, 1);
   st.flush(lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing may still be writing LDS when the workgroup's LDS is given back)
   return s;
 }
 
