@@ -233,10 +233,22 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  * extra normalisation of the IUPACPattern(ori, pwm) constructor).  Three modes (option "em_fast"):
  *   2  serial: the reference's float32 arithmetic including the ORDER in which it adds the 4^W weights of a PWM
  *      cell (src/peng.cpp:121-127) -- PWMs, iteration counts and `change` are the reference's bit for bit.  From
- *      W = 8 on a cell's chain of roundings is evaluated by a wave as a scan (csrc/seqsum.h; option
- *      "em_serial_scan" = 0 selects the dependent-addition fold; a PWM with a negative or non-finite weight is
- *      summed by a plain loop).  What a caller needs when discrete decisions follow (motif merging compares similarity
- *      scores that are exactly tied in real arithmetic for reverse-complement twins); the CLI's default.
+ *      W = 8 on a cell's chain of roundings is evaluated as a scan (csrc/seqsum.h; a PWM with a negative or non-finite
+ *      weight is summed by a plain loop).  What a caller needs when discrete decisions follow (motif merging compares
+ *      similarity scores that are exactly tied in real arithmetic for reverse-complement twins); the CLI's default.
+ *      Options of this mode (pengk_set_option):
+ *        "em_serial_scan"      how a cell's 4^(W-1) additions are carried out -- always the reference's sum, bit for bit:
+ *                              2 (default) the scan with its blocks of 4096 terms evaluated AHEAD of the chain: all
+ *                              blocks of all cells at once, each under the binade a prefix of plain block sums predicts
+ *                              for it, then one addition per block along the chain (W >= 10; below: as 1);
+ *                              1 the scan, block after block;  0 one dependent addition after the other.
+ *        "em_overlap"          with "em_serial_scan" = 2: streams the batches of PWMs take turns on, 1..4 (default 2; the
+ *                              context's own stream waits for the others before the call returns or copies).
+ *        "em_table_budget_mb"  MiB of weight tables in flight (4^W floats per PWM; twice that where the scan keeps a
+ *                              second copy in position 0's order: "em_serial_scan" = 1, W <= 10); the PWMs of a call go
+ *                              through in batches of that size.  0 (default) = automatic: 192 MiB for W <= 10 (what a
+ *                              batch writes is still in the 256 MiB Infinity Cache when it is read), above that a
+ *                              quarter of the free memory, at most 24 GiB.
  *   0  the reference's float32 terms (three divisions per k-mer weight), summed in fp64 through a fixed tree.
  *   1  (library default) the weight c*s / (1 + s/(prod/bg)) evaluated as c*s*prod / (prod + s*bg) with one
  *      reciprocal (~1 ulp per term), fp64 tree sums: the throughput mode, 2.3e12 PWM-k-mer evaluations/s.

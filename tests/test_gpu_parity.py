@@ -803,6 +803,43 @@ def test_em_serial_scan_equals_the_fold_on_large_tables(ctx, W):
     assert np.isfinite(out[1][0]).all() and not np.array_equal(out[1][0], pwms)
 
 
+def test_em_serial_batches_on_several_streams(ctx, golden_dir):
+    """Option em_overlap: the serial mode's batches of PWMs take turns on 1..4 streams (csrc/em.hip, launch_serial_ahead).
+    41 PWMs at W = 10 with a table budget of 32 MiB = batches of 8 / 4 / 2 PWMs: every stream count gives the bits of the
+    dependent-addition fold, also with PWMs that stop early (a threshold half of them meet by the third iteration) and a PWM count that leaves a ragged
+    last batch."""
+    r = cpu_pipeline(golden_dir, "mafk_w10_both")
+    W, K = r["W"], r["K"]
+    d = gpu_tables(ctx, r)
+    bg_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K].copy())
+    rng = np.random.default_rng(41)
+    pwms = rng.dirichlet(np.ones(4) * 2, size=(41, W)).astype(np.float32)
+    order = np.lexsort((np.arange(4 ** W), -r["counts"].astype(np.int64)))[:10]
+    for i, x in enumerate(order):   # ten seed-like PWMs: these converge within a few iterations
+        for p_ in range(W):
+            pwms[i, p_] = 0.1
+            pwms[i, p_, (int(x) >> (2 * p_)) & 3] = 0.7
+    out = {}
+    ctx.set_option("em_fast", 2)
+    ctx.set_option("em_table_budget_mb", 32)
+    try:
+        ctx.set_option("em_serial_scan", 0)
+        thr = float(np.median(ctx.em(W, pwms, d["counts"], bg_k, 1e4, 0.0, 3)[2]))  # half of the PWMs stop after <= 3 iterations
+        ref = ctx.em(W, pwms, d["counts"], bg_k, 1e4, thr, 6)
+        ctx.set_option("em_serial_scan", 2)
+        for streams in (1, 2, 3, 4):
+            ctx.set_option("em_overlap", streams)
+            out[streams] = ctx.em(W, pwms, d["counts"], bg_k, 1e4, thr, 6)
+    finally:
+        ctx.set_option("em_overlap", 2)
+        ctx.set_option("em_table_budget_mb", 0)
+        ctx.set_option("em_fast", 1)
+    assert len(set(ref[1].tolist())) > 1   # not all PWMs ran the same number of iterations
+    for streams, got in out.items():
+        assert got[0].tobytes() == ref[0].tobytes(), streams
+        assert got[1].tolist() == ref[1].tolist() and got[2].tobytes() == ref[2].tobytes(), streams
+
+
 @pytest.mark.parametrize("name", ["mafk100_w8_both", "mafk_w10_plus"])
 def test_em_serial_scan_equals_the_dependent_addition_fold(ctx, golden_dir, name):
     """The serial mode sums a cell's weights with a wave-wide scan (csrc/seqsum.h, option em_serial_scan = 1, default)
