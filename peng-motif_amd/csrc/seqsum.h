@@ -351,7 +351,8 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
   lds_float* bufa = lds;
   lds_float* bufb = lds + BLOCK;
   uint32_t ha = NO_BINADE, hb = NO_BINADE;  // the blocks in bufa / bufb (or on their way)
-  bool a_first = true;                      // which of the two was asked for first
+  bool a_first = true;                      // which of the two comes first in the chain
+  bool restaged = false;                    // that one was asked for again after the other: the counted wait does not cover it
 #pragma unroll 1
   for (uint32_t base = 0; base < n_blocks; base += 64u) {
     const uint4 r = reinterpret_cast<const uint4*>(rec)[base + lane];
@@ -367,6 +368,7 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
       hb = open_after(ha);
       if (hb != NO_BINADE) src.stage(hb, lane, bufb);
       a_first = true;
+      restaged = false;
     }
     uint32_t j = 0;
 #pragma unroll 1
@@ -395,7 +397,8 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
       Row mine;
       // buf1 / h1 = the block asked for first.  Block b is that one -- then its buffer is free once the rows are in
       // registers, the block behind the later one is asked for, and the later one becomes the first -- or b is a block
-      // whose binade did not hold: fetched now, through buf1, whose own block is asked for again.
+      // whose binade did not hold: fetched now, through buf1, whose own block is asked for again (and is then the
+      // YOUNGER request of the two: only vmcnt(0) covers it).
 #define PENGK_TAKE(buf1, h1, h2)                                                          \
       {                                                                                   \
         const bool ahead = h1 == b;                                                       \
@@ -403,7 +406,7 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
           src.stage(b, lane, buf1);                                                       \
           wait_loads_but<0u>();                                                           \
           PENGK_STAT_ADD(9, 1);                                                           \
-        } else if (h2 != NO_BINADE && Source::STAGE_LOADS == 16u) {                       \
+        } else if (h2 != NO_BINADE && !restaged && Source::STAGE_LOADS == 16u) {          \
           wait_loads_but<16u>();                                                          \
         } else {                                                                          \
           wait_loads_but<0u>();                                                           \
@@ -413,6 +416,9 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
         if (ahead) {                                                                      \
           h1 = open_after(h2 != NO_BINADE ? h2 : b);                                      \
           a_first = !a_first;                                                             \
+          restaged = false;                                                               \
+        } else {                                                                          \
+          restaged = h1 != NO_BINADE; /* its loads are now YOUNGER than the other buffer's */ \
         }                                                                                 \
         if (h1 != NO_BINADE) src.stage(h1, lane, buf1);                                   \
       }

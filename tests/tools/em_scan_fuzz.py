@@ -1,6 +1,6 @@
 """Differential soak of the serial EM: the scan (csrc/seqsum.h, em_serial_scan = 1) against the dependent-addition fold
 (em_serial_scan = 0) on random count tables, backgrounds and PWMs (GPU box) -- PWMs, iteration counts and `change` must be
-equal bit for bit.  usage: python tests/tools/em_scan_fuzz.py FIRST_SEED SECONDS"""
+equal bit for bit.  usage: python tests/tools/em_scan_fuzz.py FIRST_SEED SECONDS [W,W,...]   (default 8,10,10)"""
 import os
 import sys
 import time
@@ -10,13 +10,15 @@ import numpy as np
 import peng_motif_amd as pk
 
 seed0, seconds = int(sys.argv[1]), float(sys.argv[2])
+WS = [int(w) for w in sys.argv[3].split(",")] if len(sys.argv) > 3 else [8, 10, 10]
 ctx = pk.Context(0)
 ctx.set_option("em_fast", 2)
 t_end = time.time() + seconds
-seed, n_pwm_total = seed0, 0
+seed, n_pwm_total, mismatches = seed0, 0, 0
+t_print = time.time()
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
-    W = int(rng.choice([8, 10, 10]))
+    W = int(rng.choice(WS))
     NP = 4 ** W
     kind = int(rng.integers(0, 4))
     if kind == 0:      # sparse counts (a small input)
@@ -43,11 +45,25 @@ while time.time() < t_end:
         ctx.set_option("em_serial_scan", scan)
         out[scan] = ctx.em(W, pw, counts, bgd, sat, thr, it)
     ctx.set_option("em_serial_scan", 2)
-    same = all(out[k][0].tobytes() == out[0][0].tobytes() and out[k][1].tolist() == out[0][1].tolist() and out[k][2].tobytes() == out[0][2].tobytes()
-               for k in (1, 2))
-    if not same:
-        print("MISMATCH seed", seed, "W", W, "kind", kind)
-        sys.exit(1)
+    bad_modes = [k for k in (1, 2) if not (out[k][0].tobytes() == out[0][0].tobytes() and out[k][1].tolist() == out[0][1].tolist()
+                                           and out[k][2].tobytes() == out[0][2].tobytes())]
+    if bad_modes:
+        # once more, all three: which of them moves?
+        again = {}
+        for scan in (2, 1, 0):
+            ctx.set_option("em_serial_scan", scan)
+            again[scan] = ctx.em(W, pw, counts, bgd, sat, thr, it)
+        ctx.set_option("em_serial_scan", 2)
+        print("MISMATCH seed", seed, "W", W, "kind", kind, "n", n, "it", it, "thr", thr, "modes that differ from the fold:", bad_modes,
+              "; repeated run equals first run per mode:", {k: again[k][0].tobytes() == out[k][0].tobytes() for k in (2, 1, 0)})
+        mismatches += 1
+        if mismatches >= 5:
+            sys.exit(1)
     n_pwm_total += n
     seed += 1
+    if time.time() - t_print > 60:   # (a sign of life: the GPU pool takes a silent command for a hung one)
+        print("... seed", seed, "PWMs", n_pwm_total, "mismatches", mismatches, flush=True)
+        t_print = time.time()
+if mismatches:
+    sys.exit(1)
 print("EM scan fuzz: seeds %d..%d, %d PWMs, scan (blocks ahead / block after block) == dependent fold bit for bit" % (seed0, seed - 1, n_pwm_total))
