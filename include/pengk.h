@@ -244,6 +244,8 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  *                              1 the scan, block after block;  0 one dependent addition after the other.
  *        "em_overlap"          with "em_serial_scan" = 2: streams the batches of PWMs take turns on, 1..4 (default 2; the
  *                              context's own stream waits for the others before the call returns or copies).
+ *        "em_test_skew"        (test hook) n > 0: about every n-th block gets a WRONG binade estimate -- results must not
+ *                              change, only the time (the estimate never carries exactness).  0 = off.
  *        "em_table_budget_mb"  MiB of weight tables in flight (4^W floats per PWM; twice that where the scan keeps a
  *                              second copy in position 0's order: "em_serial_scan" = 1, W <= 10); the PWMs of a call go
  *                              through in batches of that size.  0 (default) = automatic: 192 MiB for W <= 10 (what a

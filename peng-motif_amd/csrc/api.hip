@@ -173,6 +173,11 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     ctx->em_serial_scan = (int)value;
     return PENGK_OK;
   }
+  if (strcmp(name, "em_test_skew") == 0) {
+    if (value < 0 || value > 1000000) return fail(PENGK_ERR_ARG, "em_test_skew must be 0 (off) or the n of 'every n-th block'");
+    ctx->em_test_skew = (int)value;
+    return PENGK_OK;
+  }
   if (strcmp(name, "em_overlap") == 0) {
     if (value < 1 || value > MAX_EM_LANES) return fail(PENGK_ERR_ARG, "em_overlap must be 1 .. %d streams", MAX_EM_LANES);
     ctx->em_overlap = (int)value;

@@ -754,10 +754,18 @@ struct BlockGeo {
 // The binade of a block from the estimates of the sum in front of it and behind it, or NO_BINADE when the two -- widened
 // by 2^-9, far more than a float32 chain of 4^13 terms drifts from the exact sum in practice -- do not share one.  A wrong
 // guess costs time, never the result (seqsum.h).
-__device__ __forceinline__ uint32_t block_binade(double before, double after) {
+__device__ __forceinline__ uint32_t block_binade(double before, double after, uint32_t skew = 0u, uint32_t key = 0u) {
   const float lo = (float)(before * (1.0 - 1.0 / 512.0)), hi = (float)(after * (1.0 + 1.0 / 512.0));
-  if (lo >= 0.0f && hi < __uint_as_float(0x7F000000u) && seqsum::binade_of(lo) == seqsum::binade_of(hi)) return seqsum::binade_of(lo);
-  return seqsum::NO_BINADE;
+  const bool sane = lo >= 0.0f && hi < __uint_as_float(0x7F000000u);
+  uint32_t e = sane && seqsum::binade_of(lo) == seqsum::binade_of(hi) ? seqsum::binade_of(lo) : seqsum::NO_BINADE;
+  // Test hook (option "em_test_skew" = n > 0): about every n-th block gets a WRONG answer -- the binade above the
+  // right one, or a binade where there is none to be had -- so that the suite exercises what a bad estimate costs
+  // (the chain's checks, its fetches on demand) far more often than real inputs do.  Results must not change.
+  if (skew != 0u && sane && ((key * 2654435761u) >> 16) % skew == 0u) {
+    if (e == seqsum::NO_BINADE) e = seqsum::binade_of(lo);
+    else if (e < 200u) e += 1u;
+  }
+  return e;
 }
 
 // The weights of a span, as em_weights_kernel computes them, and on the way the span's block sums.  A workgroup per span:
@@ -871,7 +879,8 @@ __global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __res
 // predicted by em_span_eval_kernel itself).  One wave per cell; a lane takes NBLK / 64 consecutive blocks.
 template <int W>
 __global__ __launch_bounds__(64) void em_block_predict_kernel(const int32_t* __restrict__ state, const uint32_t* __restrict__ bad,
-                                                              const float* __restrict__ sums, seqsum::BlockRecord* __restrict__ rec) {
+                                                              const float* __restrict__ sums, seqsum::BlockRecord* __restrict__ rec,
+                                                              uint32_t skew) {
   using G = BlockGeo<W>;
   const uint32_t pw = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
   if (state[2 * pw + 1] == 0 || bad[pw]) return;
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(64) void em_block_predict_kernel(const int32_t* __r
   before -= mine;
   for (uint32_t i = 0; i < PER; ++i) {
     const double after = before + (double)in[i];
-    const uint32_t e = block_binade(before, after);
+    const uint32_t e = block_binade(before, after, skew, cell * G::NBLK + lane * PER + i);
     seqsum::BlockRecord r;
     r.e = e;
     r.d0 = 0.0f;
@@ -964,7 +973,7 @@ template <int W>
 __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
                                                                             seqsum::BlockRecord* __restrict__ rec,
                                                                             const uint32_t* __restrict__ bad, uint32_t n_pwm,
-                                                                            const float* __restrict__ sums) {
+                                                                            const float* __restrict__ sums, uint32_t skew) {
   using G = BlockGeo<W>;
   // (consecutive workgroups go to consecutive XCDs: a PWM's spans, and behind them its chains, stay on one -- as in
   // em_fold_scan_kernel; 1000 PWMs x 10 iterations: 35.5 ms, with PWM = blockIdx.y 37.5)
@@ -997,7 +1006,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
         }
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
-        if (lane == 0) binade[i][wave] = block_binade((double)acc, (double)acc + (double)cs[b]);
+        if (lane == 0) binade[i][wave] = block_binade((double)acc, (double)acc + (double)cs[b], skew, cell * G::NBLK + b);
       } else {
         if (lane == 0) binade[i][wave] = cells[(size_t)cell * G::NBLK + b].e;
       }
@@ -1214,12 +1223,13 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
       hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
                          d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums);
       if (!B::PREDICT_IN_EVAL)
-        hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec);
+        hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec,
+                           (uint32_t)ctx->em_test_skew);
       const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
       const uint64_t wgs = (uint64_t)groups * B::SPANS;
       const unsigned gx = 1024u;
       hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
-                         d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums);
+                         d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums, (uint32_t)ctx->em_test_skew);
       hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, d_state + 2 * first, (const float*)tables,
                          (const seqsum::BlockRecord*)rec, partials, bad, (uint32_t)nb, done, d_pwms + (size_t)first * W * 4,
                          d_change + first, threshold, max_it);

@@ -44,6 +44,7 @@ struct pengk_ctx {
   uint64_t key_cap_override = 0; // test hook: entries per bucket region (0 = sized from the window count)
   uint64_t iupac_group_bytes = 0; // test hook: scratch budget of one group of large K4 patterns (0 = 1 GiB)
   uint64_t em_table_budget_mb = 0; // K5 serial mode: MiB of weight tables per batch of PWMs (0 = automatic)
+  int em_test_skew = 0;         // test hook: every n-th block of the serial EM gets a wrong binade estimate (em.hip, block_binade)
   int em_overlap = 2;           // K5 serial mode, em_serial_scan = 2: streams that batches of PWMs take turns on (1 .. MAX_EM_LANES)
   int em_serial_scan = 2;       // K5 serial mode: cells summed by 2 = the scan of seqsum.h with its blocks evaluated ahead of
                                 // the chain (W >= 10; else as 1), 1 = the scan, block after block, 0 = dependent additions

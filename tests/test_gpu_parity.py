@@ -803,6 +803,35 @@ def test_em_serial_scan_equals_the_fold_on_large_tables(ctx, W):
     assert np.isfinite(out[1][0]).all() and not np.array_equal(out[1][0], pwms)
 
 
+@pytest.mark.parametrize("W", [10, 12])
+@pytest.mark.parametrize("skew", [1, 2, 5])
+def test_em_serial_blocks_ahead_with_wrong_binade_estimates(ctx, W, skew):
+    """The serial mode evaluates a cell's blocks ahead of the chain under the binade an ESTIMATE of the sum predicts
+    (csrc/seqsum.h); exactness must never rest on it.  Test hook em_test_skew = n: about every n-th block is handed
+    the binade above the right one, or a binade where none is to be had (n = 1: every block) -- the chain's checks must
+    turn every one of them down and fetch the block itself.  Same bits as the dependent-addition fold, on heavy-tailed
+    counts (sums that cross many binades) and with 20 PWMs on two streams."""
+    NP = 4 ** W
+    rng = np.random.default_rng(100 * W + skew)
+    c = rng.lognormal(1.0, 2.5, NP).astype(np.uint32)
+    bg = (rng.dirichlet(np.ones(64), size=NP // 64).reshape(-1)).astype(np.float32)
+    counts, bgd = pk.DeviceArray.from_host(ctx, c), pk.DeviceArray.from_host(ctx, bg)
+    pwms = np.maximum(rng.dirichlet(np.full(4, 0.5), size=(20 if W == 10 else 4, W)).astype(np.float32), np.float32(1e-20))
+    ctx.set_option("em_fast", 2)
+    try:
+        ctx.set_option("em_serial_scan", 0)
+        ref = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 3)
+        ctx.set_option("em_serial_scan", 2)
+        ctx.set_option("em_test_skew", skew)
+        got = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 3)
+    finally:
+        ctx.set_option("em_test_skew", 0)
+        ctx.set_option("em_fast", 1)
+    assert got[0].tobytes() == ref[0].tobytes()
+    assert got[1].tolist() == ref[1].tolist() and got[2].tobytes() == ref[2].tobytes()
+    assert np.isfinite(got[0]).all()
+
+
 def test_em_serial_batches_on_several_streams(ctx, golden_dir):
     """Option em_overlap: the serial mode's batches of PWMs take turns on 1..4 streams (csrc/em.hip, launch_serial_ahead).
     41 PWMs at W = 10 with a table budget of 32 MiB = batches of 8 / 4 / 2 PWMs: every stream count gives the bits of the
