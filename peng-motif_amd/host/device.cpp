@@ -240,13 +240,14 @@ void sink_begin(void* user, size_t range_bytes, size_t n_chunks) {
   st->uploader = std::thread(upload_loop, st);
 }
 
-void sink_chunk(void* user, size_t, const SequenceChunk& c) {
+// (returns true: the chunk's byte codes are packed, the reader may give them back)
+bool sink_chunk(void* user, size_t, const SequenceChunk& c) {
   Stream* st = (Stream*)user;
-  if (c.n == 0 || !st->started) return;
+  if (c.n == 0 || !st->started) return false;
   pengk_packed pk;
   if (pengk_pack_append(c.codes, c.offs.data(), (int64_t)c.n, st->in.W, 0, &st->target, &pk) != PENGK_OK) {
     stream_fail(st, std::string("pengk_pack_append failed: ") + pengk_last_error());
-    return;
+    return false;
   }
   bool filled = false;
   {
@@ -267,6 +268,7 @@ void sink_chunk(void* user, size_t, const SequenceChunk& c) {
     }
   }
   if (filled) st->cv.notify_one();
+  return true;
 }
 }  // namespace
 

@@ -41,6 +41,10 @@ BackgroundModel::BackgroundModel(SequenceSet& sequenceSet, int order, std::vecto
                                  std::vector<std::vector<int>>, std::vector<int>) {
   init(sequenceSet, order, alpha, interpolate);
   // count over this rank's chunks of records (the counters are summed over the ranks below), chunks dealt to host threads
+  if (sequenceSet.codesReleased()) {  // (a set whose chunks went to the device comes with the packer's counters: the other constructor)
+    std::cerr << "Error: background model: the sequences are no longer held on the host" << std::endl;
+    exit(1);
+  }
   const size_t NC = sequenceSet.nChunks();
   unsigned nt = std::thread::hardware_concurrency();
   if (nt == 0) nt = 1;

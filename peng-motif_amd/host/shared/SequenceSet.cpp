@@ -298,7 +298,10 @@ SequenceSet::SequenceSet(std::string sequenceFilepath, bool single_stranded, std
 
 SequenceSet::~SequenceSet() {
   for (Sequence* s : sequences_) delete s;
-  for (SequenceChunk& c : chunks_) std::free(c.codes);
+  for (SequenceChunk& c : chunks_) {
+    std::free(c.codes);
+    std::free(c.released);
+  }
   std::free(flat_codes_);
 }
 
@@ -316,7 +319,14 @@ std::string SequenceSet::header(size_t k) const {
   return e == b ? std::to_string(k_base_ + k + 1) : std::string(c.hdr_pool.data() + b, (size_t)(e - b));
 }
 
+static void codes_gone(const std::string& path) {
+  std::cerr << "Error: the sequences of " << path << " were handed to the device while the file was read and are no longer "
+            << "held on the host (PENGK_NO_STREAMING=1 keeps them)" << std::endl;
+  exit(1);
+}
+
 std::vector<Sequence*> SequenceSet::getSequences() {
+  if (codes_released_) codes_gone(path_);
   if (!materialised_) {
     sequences_.reserve(n_local_);
     for (const SequenceChunk& c : chunks_)
@@ -335,6 +345,7 @@ std::vector<Sequence*> SequenceSet::getSequences() {
 
 void SequenceSet::flatten() {
   if (flat_codes_ || flat_offs_.size()) return;
+  if (codes_released_) codes_gone(path_);
   int64_t total = 0;
   for (const SequenceChunk& c : chunks_) total += c.n ? c.offs[c.n] : 0;
   flat_codes_ = (uint8_t*)sequence_set_huge_alloc((size_t)total);
@@ -418,6 +429,7 @@ void SequenceSet::readFASTA(const SequenceChunkSink& sink) {
     }
     if (sink.begin) sink.begin(sink.user, range, C);
     std::atomic<size_t> next{0};
+    std::atomic<bool> released{false};
     parallel_for(nt, [&](unsigned) {
       std::vector<char> text;
       std::vector<size_t> hdr;
@@ -438,9 +450,23 @@ void SequenceSet::readFASTA(const SequenceChunkSink& sink) {
         }
         // (a chunk with an error ends the run after the read: every chunk is still looked at, so that the error
         // reported is the first one in file order)
-        if (!stat[c].error && sink.chunk) sink.chunk(sink.user, c, chunks_[c]);
+        if (!stat[c].error && sink.chunk && sink.chunk(sink.user, c, chunks_[c])) {
+          // the consumer is done with the codes: their pages go back now (madvise: the address range itself stays until
+          // the set dies -- unmapping takes the process's mapping lock for writing and stalls the other readers' page
+          // faults: +0.05 s on a 2 GB file)
+          const size_t huge = (size_t)2 << 20, bytes = (size_t)stat[c].bases;
+          if (bytes >= 2 * huge) {
+            madvise(chunks_[c].codes, (bytes + huge - 1) / huge * huge, MADV_DONTNEED);
+            chunks_[c].released = chunks_[c].codes;
+          } else {
+            std::free(chunks_[c].codes);
+          }
+          chunks_[c].codes = nullptr;
+          released.store(true, std::memory_order_relaxed);
+        }
       }
     });
+    codes_released_ = released.load();
     // the first error in file order is the one a single reader would have met
     for (size_t c = 0; c < C; ++c)
       if (stat[c].error) return stat[c].error;

@@ -72,6 +72,7 @@ struct SequenceShardComm {
 // base and sends it to the GPU as it arrives (host/device.cpp), which hides packing and upload behind the read.
 struct SequenceChunk {
   uint8_t* codes = nullptr;        // byte codes of the chunk's kept records, back to back
+  uint8_t* released = nullptr;     // (their address range once a chunk consumer has taken them: pages gone, freed with the set)
   raw_vector<int64_t> offs;        // n + 1 offsets into codes (offs[0] = 0)
   raw_vector<char> hdr_pool;       // headers, compact: header k = hdr_pool[hdr_off[k] .. hdr_off[k + 1])
   raw_vector<uint64_t> hdr_off;
@@ -82,8 +83,12 @@ struct SequenceChunkSink {
   void* user = nullptr;
   // before the first chunk: `range_bytes` of FASTA text will arrive in `n_chunks` chunks (an upper bound on the bases)
   void (*begin)(void* user, size_t range_bytes, size_t n_chunks) = nullptr;
-  // from the reader's worker threads, concurrently, in any order: chunk `index` is complete
-  void (*chunk)(void* user, size_t index, const SequenceChunk& c) = nullptr;
+  // from the reader's worker threads, concurrently, in any order: chunk `index` is complete.  Returns true if the
+  // consumer has taken everything it needs from the chunk's byte codes: the reader thread then gives them back at once
+  // (records, headers and lengths stay; codes() / getSequences() of such a set end the program with a message).  2 GB of
+  // codes given back by sixteen threads while the file is still being read cost nothing; left to the end of the process
+  // they are 0.2 s of single-threaded page freeing that the caller of the program waits for.
+  bool (*chunk)(void* user, size_t index, const SequenceChunk& c) = nullptr;
 };
 
 class SequenceSet {
@@ -112,6 +117,7 @@ class SequenceSet {
   float* getBaseFrequencies() { return base_freq_; }
 
   // this rank's records, chunk by chunk, in file order
+  bool codesReleased() const { return codes_released_; }  // a chunk consumer took the byte codes (see SequenceChunkSink)
   size_t nChunks() const { return chunks_.size(); }
   const SequenceChunk& chunk(size_t i) const { return chunks_[i]; }
   // contiguous copy, made on first use (tools and callers that want one array): codes of local record i are
@@ -127,6 +133,7 @@ class SequenceSet {
   std::string diagnostics_;
   bool single_stranded_;
   std::vector<SequenceChunk> chunks_;
+  bool codes_released_ = false;
   uint8_t* flat_codes_ = nullptr;
   raw_vector<int64_t> flat_offs_;
   size_t n_global_ = 0, n_local_ = 0, k_base_ = 0;

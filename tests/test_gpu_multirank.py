@@ -38,15 +38,15 @@ def clean_env(**extra):
     return env
 
 
-def run_plain(args, tmp_path, tag="plain", timing=False):
+def run_plain(args, tmp_path, tag="plain", timing=False, extra_env=None):
     meme, js = tmp_path / (tag + ".meme"), tmp_path / (tag + ".json")
-    env = clean_env(**({"PENGK_TIMING": "1"} if timing else {}))
+    env = clean_env(**({"PENGK_TIMING": "1"} if timing else {}), **(extra_env or {}))
     r = subprocess.run([CLI] + args + ["-o", str(meme), "-j", str(js)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
                        timeout=900)
     return r.returncode, r.stdout, r.stderr, meme.read_bytes() if meme.exists() else None, js.read_bytes() if js.exists() else None
 
 
-def run_ranks(args, world, tmp_path, tag="ranks", timing=False, transport="tcp"):
+def run_ranks(args, world, tmp_path, tag="ranks", timing=False, transport="tcp", extra_env=None):
     port = free_port()
     procs = []
     for rank in range(world):
@@ -55,6 +55,7 @@ def run_ranks(args, world, tmp_path, tag="ranks", timing=False, transport="tcp")
                         PENGK_COMM_TRANSPORT=transport, PENGK_COMM_TIMEOUT="300")
         if timing:
             env["PENGK_TIMING"] = "1"
+        env.update(extra_env or {})
         procs.append((subprocess.Popen([CLI] + args + ["-o", str(meme), "-j", str(js)], stdout=subprocess.PIPE,
                                        stderr=subprocess.PIPE, env=env), meme, js))
     out = []
@@ -113,11 +114,17 @@ def test_two_ranks_on_a_synthetic_set_and_their_memory(tmp_path):
     assert [r[0] for r in res] == [0, 0], res[0][2].decode()[-2000:]
     assert (res[0][1], res[0][3], res[0][4]) == (so, meme, js)
     assert strip_timing(res[0][2]) == strip_timing(se) and res[1][1] == b""
-    base = run_ranks([small, "-w", "10"], 2, tmp_path, tag="small", timing=True)
-    whole_small = run_plain([small, "-w", "10"], tmp_path, tag="plainsmall", timing=True)
-    grow_plain = peak_rss_mb(se) - peak_rss_mb(whole_small[2])
+    # memory: with the staged path (PENGK_NO_STREAMING=1), which holds a shard's byte codes to the end -- the streaming
+    # path gives every chunk's codes back as soon as they are packed, and its peak says little about the shard
+    keep = {"PENGK_NO_STREAMING": "1"}
+    whole = run_plain([fa, "-w", "10"], tmp_path, tag="plainkeep", timing=True, extra_env=keep)
+    ranks = run_ranks([fa, "-w", "10"], 2, tmp_path, tag="rankskeep", timing=True, extra_env=keep)
+    assert (ranks[0][1], ranks[0][3], ranks[0][4]) == (so, meme, js)
+    base = run_ranks([small, "-w", "10"], 2, tmp_path, tag="small", timing=True, extra_env=keep)
+    whole_small = run_plain([small, "-w", "10"], tmp_path, tag="plainsmall", timing=True, extra_env=keep)
+    grow_plain = peak_rss_mb(whole[2]) - peak_rss_mb(whole_small[2])
     for rank in range(2):
-        grow = peak_rss_mb(res[rank][2]) - peak_rss_mb(base[rank][2])
+        grow = peak_rss_mb(ranks[rank][2]) - peak_rss_mb(base[rank][2])
         # one process: file text + codes + packed stream for 270k more records; a rank: for 135k more
         assert grow < 0.65 * grow_plain, (rank, grow, grow_plain)
 
