@@ -316,14 +316,17 @@ const PackedInput* packed_input(SequenceSet* set, int W) {
 }
 
 void shutdown() {
+  Lap lap("  ");
   if (g_stream && g_ctx) {
     if (g_stream->in.d_words) pengk_free(g_ctx, g_stream->in.d_words);
     if (g_stream->in.d_items) pengk_free(g_ctx, g_stream->in.d_items);
   }
   delete g_stream;
   g_stream = nullptr;
+  lap("device copy of the packed input released");
   if (g_ctx) pengk_destroy(g_ctx);
   g_ctx = nullptr;
+  lap("context destroyed (scratch buffers, streams)");
 }
 
 }  // namespace pengk_host

@@ -35,6 +35,8 @@ struct PhaseClock {
       while (std::fgets(line, sizeof line, f))
         if (std::strncmp(line, "VmHWM:", 6) == 0)
           std::cerr << "[timing] peak resident memory: " << std::atof(line + 6) / 1024.0 << " MiB" << std::endl;
+        else if (std::strncmp(line, "VmRSS:", 6) == 0)  // (what is left for the kernel to take back when the process ends)
+          std::cerr << "[timing] resident memory at the end: " << std::atof(line + 6) / 1024.0 << " MiB" << std::endl;
       std::fclose(f);
     }
   }
@@ -103,7 +105,8 @@ int main(int nargs, char** args) {
   // (PENGK_FULL_TEARDOWN=1 keeps the orderly release, e.g. under a leak checker.)
   pengk_host::check(pengk_synchronize(pengk_host::context()), "pengk_synchronize");
   pengk_host::finish_ranks();
-  if (std::getenv("PENGK_FULL_TEARDOWN")) {
+  const char* full_teardown = std::getenv("PENGK_FULL_TEARDOWN");
+  if (full_teardown && std::atoi(full_teardown)) {
     Global::destruct();
     pengk_host::shutdown();
     clock.lap("cleanup");
