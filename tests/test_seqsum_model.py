@@ -141,3 +141,113 @@ def test_overflow_and_zero_chains():
     check(np.full(300, 3e38, np.float32))          # +inf absorbs the rest
     check(np.concatenate([np.zeros(70, np.float32), np.full(300, 2e36, np.float32)]))
     check([])
+
+
+# ---- the blocks evaluated AHEAD of their chain (seqsum.h: block_increments, walk_chain; em.hip: block_binade) ------------
+NO_BINADE = 0xFFFFFFFF
+
+
+def binade_of(s):
+    e = bits(s) >> 23
+    return 1 if e <= 1 else e
+
+
+def bases_of_binade(e):
+    return from_bits(0 if e <= 1 else e << 23), from_bits(1 if e <= 1 else (e << 23) | 1), (e + 1) << 23
+
+
+def block_binade(before, after, wrong=False):
+    """the binade both estimates share, widened by 2^-9 -- or NO_BINADE; `wrong`: the test hook's sabotage"""
+    lo, hi = F(before * (1.0 - 1.0 / 512.0)), F(after * (1.0 + 1.0 / 512.0))
+    sane = lo >= 0 and hi < from_bits(0x7F000000)
+    e = binade_of(lo) if sane and binade_of(lo) == binade_of(hi) else NO_BINADE
+    if wrong and sane:
+        e = binade_of(lo) if e == NO_BINADE else (e + 1 if e < 200 else e)
+    return e
+
+
+def block_increments(rows, e):
+    """both bases of binade e run through the block: the two increments, or None if a base chain leaves the binade"""
+    b0, b1, limit = bases_of_binade(e)
+    base, acc = (b0, b1), (b0, b1)
+    for row in rows:
+        acc = compose(acc, (run(row, b0), run(row, b1)), base)
+    if bits(acc[0]) >= limit or bits(acc[1]) >= limit:
+        return None
+    return F(acc[0] - b0), F(acc[1] - b1)
+
+
+def ahead_sum(t, wrong_every=0):
+    """what em_weights_span / em_span_eval / em_chain do to one cell: plain block sums -> estimates -> a binade per block ->
+    increments of the blocks that got one (all at once, no chain needed) -> the chain: runs of blocks that share the
+    binade of s compose (one addition per run here: the model composes them one by one), everything else goes to
+    fold_block.  Returns (sum, blocks that took the short way)."""
+    t = np.asarray(t, np.float32)
+    pad = (-len(t)) % (ROWS * SEG)
+    t = np.concatenate([t, np.zeros(pad, np.float32)])
+    blocks = [t[b:b + ROWS * SEG].reshape(ROWS, SEG) for b in range(0, len(t), ROWS * SEG)]
+    with np.errstate(all="ignore"):
+        sums = [np.float32(np.sum(b.astype(np.float64))) for b in blocks]  # (any order: an estimate)
+        rec, before = [], 0.0
+        for i, (b, sb) in enumerate(zip(blocks, sums)):
+            e = block_binade(before, before + float(sb), wrong=bool(wrong_every) and i % wrong_every == 0)
+            inc = block_increments(b, e) if e != NO_BINADE else None
+            rec.append((e, inc) if inc is not None else (NO_BINADE, None))
+            before += float(sb)
+        s, short = F(0), 0
+        for b, (e, inc) in zip(blocks, rec):
+            if e != NO_BINADE and bits(s) < 0x7F800000 and binade_of(s) == e:
+                s2 = F(s + inc[bits(s) & 1])
+                if bits(s2) < (e + 1) << 23:   # the test fold_block applies to its last row
+                    s, short = s2, short + 1
+                    continue
+            s = fold_block(b, s)
+        return s, short
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_blocks_ahead_equal_the_sequential_sum(seed):
+    rng = np.random.default_rng(100 + seed)
+    took_short = 0
+    for _ in range(40):
+        n = int(rng.integers(200, 3000))
+        kind = rng.integers(0, 5)
+        if kind == 0:      # EM-like: heavy-tailed non-negative weights
+            t = rng.lognormal(0.0, 2.5, n).astype(np.float32)
+        elif kind == 1:    # ties: multiples of half an ulp of the running sum's binade
+            t = (rng.integers(0, 5, n) * 2.0 ** -24).astype(np.float32)
+            t[0] = 1.0
+        elif kind == 2:    # sparse with giants
+            t = np.zeros(n, np.float32)
+            idx = rng.integers(0, n, max(1, n // 10))
+            t[idx] = (rng.random(idx.size) * 10.0 ** rng.integers(-8, 8, idx.size)).astype(np.float32)
+        elif kind == 3:    # long flat stretch: the serial sum stagnates (terms below half an ulp) while the estimate grows
+            t = np.full(n, 2.0 ** -26, np.float32)
+            t[0] = 1.0
+        else:
+            t = rng.random(n, dtype=np.float32)
+        for wrong_every in (0, 1, 3):
+            with np.errstate(all="ignore"):
+                got, short = ahead_sum(t, wrong_every)
+            assert bits(got) == bits(ref_sum(t)), (seed, kind, wrong_every)
+            took_short += short if wrong_every == 0 else 0
+    assert took_short > 100   # the short way is the common one
+
+
+def test_blocks_ahead_never_trust_the_estimate():
+    """A chain whose serial sum stagnates just below 2 (every term is half an ulp: a tie, rounded to the even neighbour,
+    which is the sum itself) while its exact sum -- the estimate -- walks on past 2 and out of the margin: the estimate
+    hands the later blocks the binade of 2, the chain's sum is still in the binade of 1, the check turns the increments
+    down and fold_block reproduces the stagnation."""
+    n = 64 * 4000
+    t = np.full(n, 2.0 ** -24, np.float32)
+    t[0] = 2.0 - 2.0 ** -22   # even mantissa
+    exact = float(np.sum(t.astype(np.float64)))
+    assert exact > 2.0 * (1 + 1 / 256) and bits(ref_sum(t)) == bits(F(t[0]))
+    with np.errstate(all="ignore"):
+        got, short = ahead_sum(t)
+    assert bits(got) == bits(F(t[0]))
+    # and the estimate did mislead: blocks were evaluated for the binade of 2 that the chain never entered
+    pre = np.concatenate([[0.0], np.cumsum(t.astype(np.float64).reshape(-1, ROWS * SEG).sum(axis=1))])
+    b2 = binade_of(F(2.0))
+    assert sum(block_binade(pre[i], pre[i + 1]) == b2 for i in range(len(pre) - 1)) > 500
