@@ -75,7 +75,9 @@ int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
  * tightly; set it after pengk_set_sequences); "key_cap_override" (test hook) entries per bucket region of the
  * partitioned count, 0 = automatic; "iupac_group_bytes" (test hook) scratch budget for one group of large
  * patterns in pengk_iupac_aggregate, 0 = 1 GiB; "em_fast" 1 (default) / 0 / 2, see pengk_em.  Info: "deferred_items" (of the last pengk_count;
- * synchronises), "num_cu". */
+ * synchronises), "num_cu"; of the last pengk_em / pengk_em_device call in the serial mode with its blocks evaluated ahead
+ * (synchronise): "em_fetched_blocks" (blocks a chain added term by term), "em_mispredicted_blocks" (of those: blocks
+ * whose estimated binade did not hold), "em_restaged_blocks" / "em_restaged_waits" (csrc/seqsum.h, WalkCounts). */
 int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value);
 int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value_out);
 

@@ -128,6 +128,7 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_em_partials) (void)hipFree(ctx->d_em_partials);
   if (ctx->d_em_tables) (void)hipFree(ctx->d_em_tables);
   if (ctx->d_em_blocks) (void)hipFree(ctx->d_em_blocks);
+  if (ctx->d_em_counters) (void)hipFree(ctx->d_em_counters);
   for (int l = 0; l < 3; ++l) {
     if (ctx->em_streams[l]) (void)hipStreamDestroy(ctx->em_streams[l]);
     if (ctx->em_join[l]) (void)hipEventDestroy(ctx->em_join[l]);
@@ -220,6 +221,19 @@ int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value) {
     *value = ctx->num_cu;
     return PENGK_OK;
   }
+  // K5 serial mode, blocks ahead of their chain: what the chains of the LAST pengk_em / pengk_em_device call met, summed
+  // over all cells, PWMs and iterations (seqsum::WalkCounts; 0 for every other EM mode).  Synchronises with the stream.
+  static const char* const em_names[4] = {"em_fetched_blocks", "em_mispredicted_blocks", "em_restaged_blocks", "em_restaged_waits"};
+  for (int i = 0; i < 4; ++i)
+    if (strcmp(name, em_names[i]) == 0) {
+      unsigned long long v = 0;
+      if (ctx->d_em_counters) {
+        PENGK_HIP(hipMemcpyAsync(&v, ctx->d_em_counters + i, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+        PENGK_HIP(hipStreamSynchronize(ctx->stream));
+      }
+      *value = (int64_t)v;
+      return PENGK_OK;
+    }
   return fail(PENGK_ERR_ARG, "unknown info '%s'", name);
 }
 

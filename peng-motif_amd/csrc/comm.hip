@@ -12,7 +12,11 @@
 //    the number of records, base counts, background counters and warnings of the FASTA shards -- and hands out the
 //    RCCL id.  Every socket operation has a deadline (PENGK_COMM_TIMEOUT seconds, default 120): a rank whose peer died
 //    fails with PENGK_ERR_DEVICE instead of blocking.  Peers introduce themselves with their rank and a token derived
-//    from the launcher environment before they are counted; a stray connection is dropped and never receives anything.
+//    from the launcher environment before they are counted; a stray connection is dropped and never receives anything,
+//    and a silent one cannot hold up the real ranks (introductions are read without blocking, against the rendezvous
+//    deadline).  The token is a guard against MIX-UPS (two jobs on one host, a stale rank of an earlier run): it is a
+//    hash of public launcher values and authenticates nobody.  A job that needs more than that sets PENGK_COMM_TOKEN to
+//    a secret; without one rank 0 refuses to listen on anything but MASTER_ADDR's own interface.
 //  * the DEVICE TRANSPORT of a context: RCCL over xGMI (default; librccl is opened on first use, so single-GPU users
 //    neither link nor initialise it), or -- PENGK_COMM_TRANSPORT=tcp -- the tables staged through host memory and
 //    summed over the host channel.  RCCL cannot put two ranks on one GPU; the tcp transport exists so that the whole
@@ -33,7 +37,12 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <fcntl.h>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -111,6 +120,12 @@ int env_int(const char* name, int fallback) {
   return e && *e ? atoi(e) : fallback;
 }
 
+int load_rccl_or_test_failure(int rank) {
+  const char* t = getenv("PENGK_COMM_TEST_FAIL_LOAD");
+  if (t && *t && atoi(t) == rank) return fail(PENGK_ERR_DEVICE, "librccl not found: forced by PENGK_COMM_TEST_FAIL_LOAD");
+  return load_rccl();
+}
+
 // ---- host channel ------------------------------------------------------------------------------------------------
 double now_s() {
   timespec ts;
@@ -175,7 +190,8 @@ struct Hello {
 };
 constexpr uint64_t HELLO_MAGIC = 0x70656e676b633031ull;  // "pengkc01"
 
-// every rank of one job derives the same token from the launcher environment; PENGK_COMM_TOKEN adds a job secret
+// every rank of one job derives the same token from the launcher environment: it keeps the ranks of DIFFERENT jobs apart
+// (a mix-up guard, computable by anyone who knows the launcher values); PENGK_COMM_TOKEN adds a job secret
 uint64_t job_token(const char* addr, int port, int world) {
   std::string s = std::string("pengk|") + addr + "|" + std::to_string(port) + "|" + std::to_string(world) + "|";
   for (const char* name : {"TORCHELASTIC_RUN_ID", "PENGK_COMM_TOKEN"}) {
@@ -218,10 +234,19 @@ int chan_open(int rank, int world, const char* addr, int port, int timeout_s) {
     }
     int one = 1;
     setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-    // MASTER_ADDR's own interface, not every interface of the host; a name that resolves to an address this host does
-    // not own (NAT, a launcher quirk) falls back to all interfaces -- the token still keeps strangers out
+    // MASTER_ADDR's own interface, not every interface of the host.  A name that resolves to an address this host does
+    // not own (NAT, a launcher quirk) may fall back to all interfaces only when the job carries a secret
+    // (PENGK_COMM_TOKEN): the derived token alone is computable by anyone who can reach the port.
     bool bound = bind(ls, res->ai_addr, res->ai_addrlen) == 0;
     if (!bound && errno == EADDRNOTAVAIL) {
+      const char* secret = getenv("PENGK_COMM_TOKEN");
+      if (!secret || !*secret) {
+        close(ls);
+        freeaddrinfo(res);
+        return fail(PENGK_ERR_DEVICE,
+                    "rendezvous: %s is not an address of this host; set MASTER_ADDR to one, or PENGK_COMM_TOKEN to a job secret "
+                    "to listen on all interfaces", addr);
+      }
       sockaddr_in sa{};
       sa.sin_family = AF_INET;
       sa.sin_addr.s_addr = htonl(INADDR_ANY);
@@ -234,29 +259,81 @@ int chan_open(int rank, int world, const char* addr, int port, int timeout_s) {
       return fail(PENGK_ERR_DEVICE, "rendezvous: cannot listen on %s:%d", addr, port);
     }
     g_chan.fds.assign((size_t)world, -1);
+    // Connections that have not introduced themselves yet wait in a pending set and are read without blocking: a silent
+    // or slow connection costs the real ranks nothing, and is dropped after 5 s (or when the set is full).
+    struct Pending {
+      int fd;
+      double drop_at;
+      size_t got;
+      Hello h;
+    };
+    std::vector<Pending> pending;
+    auto drop_pending = [&]() {
+      for (Pending& p : pending) close(p.fd);
+      pending.clear();
+    };
     int have = 0;
     while (have < world - 1) {
-      const double left = deadline - now_s();
-      pollfd pf{ls, POLLIN, 0};
-      if (left <= 0 || poll(&pf, 1, (int)(left * 1000) + 1) <= 0) {
+      const double now = now_s();
+      double wake = deadline;
+      for (const Pending& p : pending) wake = p.drop_at < wake ? p.drop_at : wake;
+      std::vector<pollfd> pfs(1 + pending.size());
+      pfs[0] = pollfd{ls, POLLIN, 0};
+      for (size_t i = 0; i < pending.size(); ++i) pfs[1 + i] = pollfd{pending[i].fd, POLLIN, 0};
+      const double left = wake - now;
+      const int ready = now >= deadline ? -1 : poll(pfs.data(), (nfds_t)pfs.size(), left > 0 ? (int)(left * 1000) + 1 : 0);
+      if (ready < 0 && (now >= deadline || errno != EINTR)) {
         close(ls);
+        drop_pending();
         chan_close();
         return fail(PENGK_ERR_DEVICE, "rendezvous: only %d of %d ranks reached %s:%d within %d s", have + 1, world, addr, port,
                     timeout_s);
       }
-      const int fd = accept(ls, nullptr, nullptr);
-      if (fd < 0) continue;
-      set_io_deadline(fd, 5);  // a connection that does not introduce itself at once is not a rank
-      Hello h{};
-      if (recv_all(fd, &h, sizeof h) != 0 || h.magic != HELLO_MAGIC || h.token != token || h.world != (uint32_t)world ||
-          h.rank == 0 || h.rank >= (uint32_t)world || g_chan.fds[h.rank] >= 0) {
-        close(fd);
-        continue;
+      if (ready < 0) continue;
+      std::vector<Pending> keep;
+      for (size_t i = 0; i < pending.size(); ++i) {
+        Pending p = pending[i];
+        bool done = false, bad = false;
+        if (pfs[1 + i].revents & (POLLIN | POLLHUP | POLLERR)) {
+          const ssize_t k = recv(p.fd, (char*)&p.h + p.got, sizeof(Hello) - p.got, MSG_DONTWAIT);
+          if (k > 0) {
+            p.got += (size_t)k;
+            done = p.got == sizeof(Hello);
+          } else if (k == 0 || (errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR)) {
+            bad = true;
+          }
+        }
+        if (done) {
+          const Hello& h = p.h;
+          if (h.magic != HELLO_MAGIC || h.token != token || h.world != (uint32_t)world || h.rank == 0 || h.rank >= (uint32_t)world ||
+              g_chan.fds[h.rank] >= 0) {
+            close(p.fd);
+          } else {
+            set_io_deadline(p.fd, timeout_s);
+            g_chan.fds[h.rank] = p.fd;
+            ++have;
+          }
+        } else if (bad || now_s() >= p.drop_at) {
+          close(p.fd);
+        } else {
+          keep.push_back(p);
+        }
       }
-      set_io_deadline(fd, timeout_s);
-      g_chan.fds[h.rank] = fd;
-      ++have;
+      pending.swap(keep);
+      if (pfs[0].revents & POLLIN) {
+        const int fd = accept(ls, nullptr, nullptr);
+        if (fd >= 0) {
+          if (pending.size() >= (size_t)world + 64) {  // more strangers than a job has ranks: the oldest goes
+            close(pending.front().fd);
+            pending.erase(pending.begin());
+          }
+          int one = 1;
+          setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+          pending.push_back(Pending{fd, now_s() + 5.0, 0, Hello{}});
+        }
+      }
     }
+    drop_pending();
     close(ls);
     for (int r = 1; r < world; ++r)  // everyone is here: release the peers
       if (send_all(g_chan.fds[r], &HELLO_MAGIC, sizeof HELLO_MAGIC) != 0) return chan_fail("rendezvous: a rank left %s:%d", addr, port);
@@ -436,14 +513,57 @@ int pengk_comm_init(pengk_ctx* ctx, const void* id_bytes, int rank, int world) {
   if (rc) return rc;
   rc = enter(ctx);
   if (rc) return rc;
-  rccl_unique_id id;
-  memcpy(&id, id_bytes, sizeof id);
-  rccl_comm comm = nullptr;
-  PENGK_RCCL(g_rccl.CommInitRank(&comm, world, id, rank));
-  ctx->comm = comm;
+  // ncclCommInitRank blocks until every rank of the id has entered it and has no deadline of its own: a rank that
+  // never arrives (it failed to load librccl, died, or belongs to another job) would park the others for good.  The
+  // call therefore runs on a helper thread and this one waits for it PENGK_COMM_TIMEOUT seconds; past the deadline
+  // the rank reports the error (the helper is left behind: the process is expected to exit, as after any comm error).
+  struct InitCall {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    int result = 0;
+    rccl_comm comm = nullptr;
+    rccl_unique_id id;
+    int device = 0, rank = 0, world = 1;
+  };
+  auto call = std::make_shared<InitCall>();
+  memcpy(&call->id, id_bytes, sizeof call->id);
+  call->device = ctx->device;
+  call->rank = rank;
+  call->world = world;
+  const int timeout_s = env_int("PENGK_COMM_TIMEOUT", 120) < 1 ? 1 : env_int("PENGK_COMM_TIMEOUT", 120);
+  std::thread([call]() {
+    int r = hipSetDevice(call->device) == hipSuccess ? 0 : -1;
+    rccl_comm comm = nullptr;
+    if (r == 0) r = g_rccl.CommInitRank(&comm, call->world, call->id, call->rank);
+    std::lock_guard<std::mutex> lock(call->mu);
+    call->result = r;
+    call->comm = comm;
+    call->done = true;
+    call->cv.notify_all();
+  }).detach();
+  {
+    std::unique_lock<std::mutex> lock(call->mu);
+    if (!call->cv.wait_for(lock, std::chrono::seconds(timeout_s), [&] { return call->done; }))
+      return fail(PENGK_ERR_DEVICE, "ncclCommInitRank: rank %d of %d still waiting for the other ranks after %d s", rank, world,
+                  timeout_s);
+    if (call->result != 0)
+      return fail(PENGK_ERR_DEVICE, "ncclCommInitRank: %s", call->result < 0 ? "hipSetDevice failed" : g_rccl.GetErrorString(call->result));
+    ctx->comm = call->comm;
+  }
   ctx->comm_transport = PENGK_TRANSPORT_RCCL;
   ctx->comm_rank = rank;
   ctx->comm_world = world;
+  return PENGK_OK;
+}
+
+// every rank contributes one status word over the host channel; the first failing rank (if any) is named to all of them
+static int chan_agree(int32_t mine, const char* what) {
+  std::vector<int32_t> all((size_t)g_chan.world, 0);
+  int rc = chan_allgather(&mine, all.data(), sizeof mine);
+  if (rc) return rc;
+  for (int r = 0; r < g_chan.world; ++r)
+    if (all[(size_t)r] != 0) return r == g_chan.rank ? mine : fail(PENGK_ERR_DEVICE, "rank %d %s", r, what);
   return PENGK_OK;
 }
 
@@ -463,21 +583,37 @@ int pengk_comm_init_env(pengk_ctx* ctx) {
   }
   if (transport && *transport && strcmp(transport, "rccl") != 0)
     return fail(PENGK_ERR_ARG, "PENGK_COMM_TRANSPORT=%s (rccl or tcp)", transport);
-  // every rank learns whether rank 0 could produce an id before anybody enters ncclCommInitRank
+  // Nobody enters ncclCommInitRank before EVERY rank has said, over the host channel (which has deadlines), that it
+  // can: librccl loaded on all of them, the id created on rank 0.  PENGK_COMM_TEST_FAIL_LOAD=<rank> is the test hook
+  // that makes one rank fail here (tests/test_host_channel_cpu.py).
+  int32_t loaded = load_rccl_or_test_failure(rank);
+  rc = chan_agree(loaded, "could not load librccl");
+  if (rc) return rc;
   struct {
     int32_t rc;
     rccl_unique_id id;
   } msg;
   memset(&msg, 0, sizeof msg);
-  if (rank == 0) {
-    msg.rc = load_rccl();
-    if (!msg.rc && g_rccl.GetUniqueId(&msg.id) != 0) msg.rc = fail(PENGK_ERR_DEVICE, "ncclGetUniqueId failed");
-  }
+  if (rank == 0 && g_rccl.GetUniqueId(&msg.id) != 0) msg.rc = fail(PENGK_ERR_DEVICE, "ncclGetUniqueId failed");
   rc = chan_bcast(&msg, sizeof msg);
-  lock.unlock();
   if (rc) return rc;
   if (msg.rc) return rank == 0 ? msg.rc : fail(PENGK_ERR_DEVICE, "rank 0 could not create an RCCL id");
-  return pengk_comm_init(ctx, &msg.id, rank, world);
+  lock.unlock();
+  const int32_t inited = pengk_comm_init(ctx, &msg.id, rank, world);
+  // ... and nobody USES the communicator before every rank has one: a one-sided failure inside ncclCommInitRank
+  // surfaces on all ranks here, within the host channel's deadline
+  lock.lock();
+  rc = chan_agree(inited, "could not create its RCCL communicator");
+  lock.unlock();
+  if (rc && !inited) {
+    // this rank has a communicator, another one has not: it is abandoned, not destroyed (ncclCommDestroy may wait for
+    // the peers that never joined); the caller reports the error and the process ends
+    ctx->comm = nullptr;
+    ctx->comm_transport = PENGK_TRANSPORT_NONE;
+    ctx->comm_rank = 0;
+    ctx->comm_world = 1;
+  }
+  return rc;
 }
 
 int pengk_comm_info(pengk_ctx* ctx, int* rank_out, int* world_out) {

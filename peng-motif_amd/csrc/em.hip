@@ -1055,12 +1055,13 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
                                                       const seqsum::BlockRecord* __restrict__ rec, double* __restrict__ partials,
                                                       uint32_t* __restrict__ bad, uint32_t n_pwm, uint32_t* __restrict__ done,
                                                       float* __restrict__ pwms, float* __restrict__ change_out, float threshold,
-                                                      int max_it) {
+                                                      int max_it, unsigned long long* __restrict__ counters) {
   using G = BlockGeo<W>;
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
   if (pw >= n_pwm || state[2 * pw + 1] == 0) return;
   __shared__ __attribute__((aligned(16))) float lds[seqsum::WALK_LDS_FLOATS];
+  seqsum::WalkCounts wc;
   const uint32_t lane = threadIdx.x;
   const seqsum::BlockRecord* r = rec + ((size_t)pw * G::CELLS + cell) * G::NBLK;
   float s = 0.0f;
@@ -1069,11 +1070,11 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
   } else if ((cell >> 2) == 0u) {
     EmTerms0<W> src0{w, cell & 3u};
     src0.bind_stage(lane);
-    s = seqsum::walk_chain(src0, r, G::NBLK, (seqsum::lds_float*)lds, lane);
+    s = seqsum::walk_chain(src0, r, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
   } else {
     EmTerms<W> src{w, cell >> 2, cell & 3u};
     src.bind_stage(lane);
-    s = seqsum::walk_chain(src, r, G::NBLK, (seqsum::lds_float*)lds, lane);
+    s = seqsum::walk_chain(src, r, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
   }
   // the PWM's last cell to arrive does what em_finalize_kernel does (one launch less per iteration)
   // No fences (a device-scope release writes the XCD's whole L2 back): the sum is stored by a device-scope atomic, which
@@ -1081,6 +1082,11 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
   // sums with device-scope loads.
   uint32_t arrived = 0;
   if (lane == 0) {
+    // what this chain met (pengk_get_info "em_fetched_blocks" ...): four relaxed adds per chain, nobody waits for them
+    if (wc.fetched) __hip_atomic_fetch_add(counters + 0, (unsigned long long)wc.fetched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.mispredicted) __hip_atomic_fetch_add(counters + 1, (unsigned long long)wc.mispredicted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.restaged) __hip_atomic_fetch_add(counters + 2, (unsigned long long)wc.restaged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.restaged_waits) __hip_atomic_fetch_add(counters + 3, (unsigned long long)wc.restaged_waits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(partials + (size_t)pw * (W * 4) + cell),
                                 (unsigned long long)__double_as_longlong((double)s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1088,6 +1094,13 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
   }
   arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
   if (arrived != G::CELLS - 1u) return;
+  // The one finalizing wave of a PWM: everything it reads below was written by other workgroups of THIS launch before
+  // their fetch_add on done[pw] (the exchange on `partials` returned first).  The acquire fence makes that order explicit
+  // for the compiler and the cache (one L2 invalidate per PWM, no write-back -- a release on the 4 W producers would write
+  // every XCD's L2 back and tripled the kernel).  What relies on the kernel boundary instead: the plain stores to
+  // done[pw], bad[pw], state[], pwms[] and change_out[] below are read by the NEXT launch on this stream only.
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("" ::: "memory");
   if (lane == 0) done[pw] = 0u;
   finalize_pwm<W, 16>((int)pw, pwms, state, change_out, partials, threshold, max_it, bad, wbuf, G::NP, lds);
 }
@@ -1168,6 +1181,7 @@ namespace {
 // against 0.96 on one stream.  Starting the second lane when the first one's chains start, so that chains run beside
 // weights, was measured: 0.99 ms -- a chain's 32 KiB of LDS per wave halve the evaluation kernel's workgroups per CU.)
 // (PWMs are independent; every batch has its own tables, records and sums.)  `budget` = bytes of weight tables in flight.
+constexpr int EM_COUNTERS = 4;  // fetched, mispredicted, restaged, restaged_waits (seqsum::WalkCounts)
 template <int W>
 int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
                         const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change, size_t budget) {
@@ -1178,9 +1192,14 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   // 10 iterations at W = 10 take 1.00 / 0.91 / 0.96 / 0.98 ms on 1 / 2 / 3 / 4 streams, 1000 PWMs 43 / 37.5 / 38.6 / 38.1 ms)
   int lanes = ctx->em_overlap < 1 ? 1 : ctx->em_overlap > MAX_EM_LANES ? MAX_EM_LANES : ctx->em_overlap;
   while (lanes > 1 && n_pwm < 8 * (int64_t)lanes) --lanes;
-  int64_t batch = (int64_t)(budget / lanes / (np * sizeof(float)));
-  if (batch < 1) batch = 1;
-  if (batch * lanes > n_pwm) batch = lanes > 1 ? ((n_pwm + lanes - 1) / lanes + 7) / 8 * 8 : n_pwm;  // (whole groups of 8 PWMs: one per XCD)
+  const int64_t fit = std::max<int64_t>(1, (int64_t)(budget / lanes / (np * sizeof(float))));  // tables the budget holds per lane
+  int64_t batch = fit;
+  if (batch * lanes > n_pwm) {
+    // fewer PWMs than the lanes could hold: equal shares, in whole groups of 8 PWMs (one per XCD) -- but never more
+    // tables than the budget (17 PWMs on 2 lanes with room for 9 each: 8 + 8 + 1 in three turns, not 2 x 16)
+    batch = lanes > 1 ? ((n_pwm + lanes - 1) / lanes + 7) / 8 * 8 : n_pwm;
+    if (batch > fit) batch = fit >= 8 ? fit / 8 * 8 : fit;
+  }
   if (batch > 65528) batch = 65528;  // gridDim.y
   // per lane: tables | cell sums, flags ("has a weight the scan cannot take"), arrival counters | block sums, records
   const size_t tables_b = (size_t)batch * np * sizeof(float);
@@ -1193,6 +1212,8 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   if (rc) return rc;
   rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes, lanes * blocks_b);
   if (rc) return rc;
+  if (!ctx->d_em_counters) PENGK_HIP(hipMalloc((void**)&ctx->d_em_counters, EM_COUNTERS * sizeof(unsigned long long)));
+  PENGK_HIP(hipMemsetAsync(ctx->d_em_counters, 0, EM_COUNTERS * sizeof(unsigned long long), ctx->stream));  // per pengk_em call
   hipStream_t streams[MAX_EM_LANES];
   streams[0] = ctx->stream;
   for (int l = 1; l < lanes; ++l) {
@@ -1208,39 +1229,49 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
     PENGK_HIP(hipEventRecord(ctx->em_fork, ctx->stream));
     for (int l = 1; l < lanes; ++l) PENGK_HIP(hipStreamWaitEvent(streams[l], ctx->em_fork, 0));
   }
-  int64_t chunk = 0;
-  for (int64_t first = 0; first < n_pwm; first += batch, ++chunk) {
-    const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
-    const int l = (int)(chunk % lanes);
-    hipStream_t st = streams[l];
-    float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_tables) + l * tables_b);
-    double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->d_em_partials) + l * partials_b);
-    uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(partials) + flags_at);
-    uint32_t* done = bad + batch;
-    float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * blocks_b);
-    seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
-    for (int it = 0; it < max_it; ++it) {
-      hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
-                         d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums);
-      if (!B::PREDICT_IN_EVAL)
-        hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec,
-                           (uint32_t)ctx->em_test_skew);
-      const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
-      const uint64_t wgs = (uint64_t)groups * B::SPANS;
-      const unsigned gx = 1024u;
-      hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
-                         d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums, (uint32_t)ctx->em_test_skew);
-      hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, d_state + 2 * first, (const float*)tables,
-                         (const seqsum::BlockRecord*)rec, partials, bad, (uint32_t)nb, done, d_pwms + (size_t)first * W * 4,
-                         d_change + first, threshold, max_it);
+  // Once the lanes are forked they are ALWAYS joined, also when a launch fails half way: the caller reads and frees
+  // buffers on ctx->stream, and kernels may still run on the other streams.
+  const int rc_launch = [&]() -> int {
+    int64_t chunk = 0;
+    for (int64_t first = 0; first < n_pwm; first += batch, ++chunk) {
+      const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
+      const int l = (int)(chunk % lanes);
+      hipStream_t st = streams[l];
+      float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_tables) + l * tables_b);
+      double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->d_em_partials) + l * partials_b);
+      uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(partials) + flags_at);
+      uint32_t* done = bad + batch;
+      float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * blocks_b);
+      seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
+      for (int it = 0; it < max_it; ++it) {
+        hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
+                           d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums);
+        if (!B::PREDICT_IN_EVAL)
+          hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec,
+                             (uint32_t)ctx->em_test_skew);
+        const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
+        const uint64_t wgs = (uint64_t)groups * B::SPANS;
+        const unsigned gx = 1024u;
+        hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
+                           d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums, (uint32_t)ctx->em_test_skew);
+        hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, d_state + 2 * first, (const float*)tables,
+                           (const seqsum::BlockRecord*)rec, partials, bad, (uint32_t)nb, done, d_pwms + (size_t)first * W * 4,
+                           d_change + first, threshold, max_it, ctx->d_em_counters);
+      }
+      PENGK_HIP(hipGetLastError());
     }
-    PENGK_HIP(hipGetLastError());
-  }
+    return PENGK_OK;
+  }();
+  int rc_join = PENGK_OK;
   for (int l = 1; l < lanes; ++l) {
-    PENGK_HIP(hipEventRecord(ctx->em_join[l - 1], streams[l]));
-    PENGK_HIP(hipStreamWaitEvent(ctx->stream, ctx->em_join[l - 1], 0));
+    hipError_t e = hipEventRecord(ctx->em_join[l - 1], streams[l]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->em_join[l - 1], 0);
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(streams[l]);  // the join could not be enqueued: wait here instead
+      if (!rc_join) rc_join = hip_fail(e, "joining the EM's streams");
+    }
   }
-  return PENGK_OK;
+  return rc_launch ? rc_launch : rc_join;
 }
 
 #ifndef PENGK_EM_BUDGET_GIB

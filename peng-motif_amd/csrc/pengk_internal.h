@@ -28,6 +28,7 @@ struct pengk_ctx {
   size_t em_tables_bytes = 0;
   void* d_em_blocks = nullptr;   // K5 serial mode, blocks ahead of their chain: block sums | block records (em.hip)
   size_t em_blocks_bytes = 0;
+  unsigned long long* d_em_counters = nullptr;  // K5 serial mode: what the chains of the last pengk_em call met (seqsum::WalkCounts)
   hipStream_t em_streams[3] = {nullptr, nullptr, nullptr};  // K5 serial mode: the streams beside `stream` that batches of PWMs take turns on
   hipEvent_t em_fork = nullptr, em_join[3] = {nullptr, nullptr, nullptr};
   void* d_misc = nullptr;  // small staging buffer

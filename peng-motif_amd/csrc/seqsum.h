@@ -334,6 +334,13 @@ struct BlockRecord {
 // block another kernel wrote), and with loads into registers -- where the compiler places the waits, vmcnt(0) whenever
 // it cannot count -- the chain stood waiting at every fetched block.  lds = two buffers of BLOCK floats.
 constexpr uint32_t WALK_LDS_FLOATS = 2u * BLOCK;
+// -DPENGK_TEST_WALK_RACE re-creates round 3's defect (the counted wait also for a re-requested block): a developer build
+// that exists to show that test_em_chain_walk_restaged_block_is_pinned fails on it; never part of the product build.
+#ifdef PENGK_TEST_WALK_RACE
+#define PENGK_WALK_RESTAGED(x) false
+#else
+#define PENGK_WALK_RESTAGED(x) (x)
+#endif
 template <uint32_t N>
 __device__ __forceinline__ void wait_loads_but() {  // until at most N of this wave's loads are outstanding
   static_assert(N == 0u || N == 16u, "the counts walk_chain needs");
@@ -342,9 +349,18 @@ __device__ __forceinline__ void wait_loads_but() {  // until at most N of this w
   else
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
+// What a chain met on its way (wave-uniform; the kernel adds them up per pengk_em call, pengk_get_info "em_*"):
+//   fetched      blocks taken the long way (fold_block on the block's terms): the ones without a binade + the mispredicted
+//   mispredicted blocks that HAD a binade which did not hold when the chain got there: fetched on demand
+//   restaged     ... through the buffer of a block already asked for, which is then asked for again
+//   restaged_waits  takes of such a re-requested block while the other buffer's (older) loads were still counted: the
+//                   wait that must be vmcnt(0), not the counted one (the round-3 defect: tests/test_gpu_parity.py pins it)
+struct WalkCounts {
+  uint32_t fetched = 0, mispredicted = 0, restaged = 0, restaged_waits = 0;
+};
 template <class Source>
 __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord* __restrict__ rec, uint32_t n_blocks, lds_float* lds,
-                                            uint32_t lane) {
+                                            uint32_t lane, WalkCounts& wc) {
   Stats st;
   const unsigned long long w0 = PENGK_CLOCK();
   float s = 0.0f;
@@ -406,9 +422,11 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
           src.stage(b, lane, buf1);                                                       \
           wait_loads_but<0u>();                                                           \
           PENGK_STAT_ADD(9, 1);                                                           \
-        } else if (h2 != NO_BINADE && !restaged && Source::STAGE_LOADS == 16u) {          \
+          ++wc.mispredicted;                                                              \
+        } else if (h2 != NO_BINADE && !PENGK_WALK_RESTAGED(restaged) && Source::STAGE_LOADS == 16u) { \
           wait_loads_but<16u>();                                                          \
         } else {                                                                          \
+          wc.restaged_waits += (h2 != NO_BINADE && restaged) ? 1u : 0u;                   \
           wait_loads_but<0u>();                                                           \
         }                                                                                 \
         mine.read_staged(buf1, lane);                                                     \
@@ -419,6 +437,7 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
           restaged = false;                                                               \
         } else {                                                                          \
           restaged = h1 != NO_BINADE; /* its loads are now YOUNGER than the other buffer's */ \
+          wc.restaged += restaged ? 1u : 0u;                                              \
         }                                                                                 \
         if (h1 != NO_BINADE) src.stage(h1, lane, buf1);                                   \
       }
@@ -432,6 +451,7 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
 #endif
       PENGK_STAT_ADD(3, PENGK_CLOCK() - c1);
       PENGK_STAT_ADD(0, 1);
+      ++wc.fetched;
       ++j;
     }
   }

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <new>
 #include <string>
@@ -91,6 +92,29 @@ BasePattern::BasePattern(const size_t pattern_length, Strand s, const int k, con
   uint64_t lt = 0;
   d_ltot.download(&lt, 1);
   ltot = lt;
+
+  // Test hook (tests/test_gpu_multirank.py): rank 0 leaves the GLOBAL tables as files, so that a multi-rank run can be
+  // compared with the compiled reference's per-shard sums (tests/golden/shard_prefix_checksums.json), not just with
+  // this program's own single-process run.
+  if (const char* dir = std::getenv("PENGK_DUMP_TABLES")) {
+    if (pengk_host::rank() == 0) {
+      auto dump = [&](const char* name, const void* p, size_t bytes) {
+        const std::string path = std::string(dir) + "/" + name;
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f || fwrite(p, 1, bytes, f) != bytes) {
+          std::cerr << "Error: PENGK_DUMP_TABLES: cannot write " << path << std::endl;
+          exit(1);
+        }
+        fclose(f);
+      };
+      dump("counts.u32", host_counts32(), NP * sizeof(uint32_t));
+      dump("z.f32", host_zscore(), NP * sizeof(float));
+      dump("expected.f32", host_expected(), NP * sizeof(float));
+      dump("V.f32", hV, sizeof hV);
+      const std::string meta = "ltot " + std::to_string(ltot) + "\nN " + std::to_string(n_sequences) + "\n";
+      dump("meta.txt", meta.data(), meta.size());
+    }
+  }
 }
 
 BasePattern::~BasePattern() {

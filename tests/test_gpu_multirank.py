@@ -184,3 +184,87 @@ def test_ranks_on_degenerate_inputs(tmp_path, text):
     assert [r[0] for r in res] == [rc] * 3, [r[2].decode()[-300:] for r in res]
     assert (res[0][1], res[0][2], res[0][3], res[0][4]) == (so, se, meme, js)
     assert res[1][1] == res[2][1] == b""
+
+
+def test_a_rank_without_rccl_ends_every_rank_before_anyone_enters_comminit(tmp_path):
+    """RCCL transport, two ranks, rank 1 cannot load librccl (PENGK_COMM_TEST_FAIL_LOAD): every rank reports its
+    load_rccl() result over the host channel BEFORE anybody enters ncclCommInitRank (which has no deadline of its own),
+    so both ranks end with the error at once -- rank 0 naming rank 1 -- instead of rank 0 waiting inside RCCL."""
+    port = free_port()
+    import time
+    t0 = time.time()
+    procs = []
+    for rank in range(2):
+        env = clean_env(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                        PENGK_COMM_TRANSPORT="rccl", PENGK_COMM_TIMEOUT="60", PENGK_COMM_TEST_FAIL_LOAD="1")
+        procs.append(subprocess.Popen([CLI, os.path.join(GOLD, "MafK_100seqs.fasta"), "-w", "8"], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, env=env))
+    res = [p.communicate(timeout=120) + (p.returncode,) for p in procs]
+    assert time.time() - t0 < 50  # far inside the 60 s deadline: nobody waited for anybody
+    assert [r[2] for r in res] == [1, 1], res
+    assert b"rank 1 could not load librccl" in res[0][1], res[0][1][-600:]
+    assert b"forced by PENGK_COMM_TEST_FAIL_LOAD" in res[1][1], res[1][1][-600:]
+
+
+def test_comminit_has_a_deadline():
+    """pengk_comm_init with an id whose other rank never joins: an error after PENGK_COMM_TIMEOUT seconds, not a process
+    parked inside ncclCommInitRank (the call runs on a helper thread; the process leaves with os._exit, as a rank does
+    after any communicator error)."""
+    code = r"""
+import ctypes as C, os, sys, time
+sys.path.insert(0, %r)
+import peng_motif_amd as pk
+L = pk.lib()
+ctx = pk.Context(0)
+buf = C.create_string_buffer(128)
+pk._check(L.pengk_comm_unique_id(buf))
+t0 = time.time()
+rc = L.pengk_comm_init(ctx.h, buf.raw, 0, 2)
+print("RC", rc, "%%.1f" %% (time.time() - t0), L.pengk_last_error().decode(), flush=True)
+os._exit(0)
+""" % ROOT
+    import sys
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=clean_env(PENGK_COMM_TIMEOUT="4"), timeout=180)
+    out = r.stdout.decode()
+    line = [l for l in out.splitlines() if l.startswith("RC ")]  # (librccl announces its version on stdout as well)
+    assert r.returncode == 0 and len(line) == 1, (out, r.stderr.decode()[-800:])
+    rc, secs = line[0].split()[1:3]
+    assert int(rc) != 0 and 3.5 <= float(secs) < 30 and "still waiting for the other ranks" in line[0], out
+
+
+def _prefix_row(job, k):
+    import json
+    rows = json.load(open(os.path.join(GOLD, "shard_prefix_checksums.json")))
+    row, = [r for r in rows if r["job"] == job and r["kind"] == "prefix" and r["k"] == k]
+    return row
+
+
+@pytest.mark.parametrize("job,k,world", [("configs2_weak", 2, 2), ("configs2_weak", 4, 4), ("configs3", 2, 2), ("configs3", 4, 4)])
+def test_ranks_produce_the_sum_of_the_references_shard_tables(tmp_path, job, k, world):
+    """The multi-rank CLI against the COMPILED REFERENCE, not against this program's own single-process run: the first k
+    shards of BASELINE configs[3] (k x 12.5M x 200 bp, W = 12) / of bench.py's weak-scaled configs[2] sets (k x 10M x 200 bp,
+    W = 10) as one FASTA file, read by `world` ranks (byte ranges), counted, summed over the exchange step; rank 0's global
+    count table, ltot, V and z must be what the reference's per-shard tables add up to
+    (tests/golden/shard_prefix_checksums.json; V and z: the oracle's sweep on those sums)."""
+    import hashlib
+    import shutil
+    row = _prefix_row(job, k)
+    need_gb = row["n_seq"] * (row["L"] + 12) / 1e9 * 1.1
+    if shutil.disk_usage(str(tmp_path)).free / 1e9 < need_gb + 2:
+        pytest.skip("needs %.0f GB of scratch for the FASTA file" % need_gb)
+    fa = str(tmp_path / "set.fa")
+    subprocess.check_call([SYNTH, fa, str(row["n_seq"]), str(row["L"]), str(row["seed"]), "0"])
+    dump = tmp_path / "tables"
+    dump.mkdir()
+    args = [fa, "-w", str(row["W"])] + (["--strand", "PLUS"] if row["strand"] == "PLUS" else [])
+    res = run_ranks(args, world, tmp_path, extra_env={"PENGK_DUMP_TABLES": str(dump)})
+    os.remove(fa)
+    assert [r[0] for r in res] == [0] * world, res[0][2].decode()[-2000:]
+    sha = lambda name: hashlib.sha256((dump / name).read_bytes()).hexdigest()  # noqa: E731
+    meta = dict(l.split() for l in (dump / "meta.txt").read_text().splitlines())
+    assert int(meta["ltot"]) == row["ltot"] and int(meta["N"]) == row["n_seq"]
+    assert sha("counts.u32") == row["sha_counts_u32"]
+    assert sha("V.f32") == row["sha_V"]
+    assert sha("expected.f32") == row["sha_expected"]
+    assert sha("z.f32") == row["sha_z"]

@@ -824,12 +824,98 @@ def test_em_serial_blocks_ahead_with_wrong_binade_estimates(ctx, W, skew):
         ctx.set_option("em_serial_scan", 2)
         ctx.set_option("em_test_skew", skew)
         got = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 3)
+        met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks", "restaged_blocks", "restaged_waits")}
     finally:
         ctx.set_option("em_test_skew", 0)
         ctx.set_option("em_fast", 1)
     assert got[0].tobytes() == ref[0].tobytes()
     assert got[1].tolist() == ref[1].tolist() and got[2].tobytes() == ref[2].tobytes()
     assert np.isfinite(got[0]).all()
+    # ... and the branches in question did run: blocks whose binade did not hold were fetched on demand, some of them
+    # through the buffer of a block already asked for (which is then asked for again: the walk's `restaged` state)
+    cells = len(pwms) * 4 * W * 3
+    assert met["mispredicted_blocks"] > cells and met["fetched_blocks"] > met["mispredicted_blocks"], met
+    assert met["restaged_blocks"] > 0, met
+    if W == 12:
+        assert met["restaged_waits"] > 0, met
+
+
+def _ramp_counts(W, doublings=30, blocks_per_doubling=16):
+    """A count table whose running sums cross a power of two about every `blocks_per_doubling` blocks of EVERY cell's
+    chain (a block = 4096 terms of a cell = 16384 consecutive x), `doublings` times, then stay flat: several blocks
+    without a binade in most 64-block chunks of the first part of a chain -- what the chain walk's double buffering and
+    its re-requests are there for, and what real count tables produce once in a few thousand PWMs."""
+    x = np.arange(4 ** W, dtype=np.float64)
+    period = blocks_per_doubling * 16384.0
+    return np.floor(2.0 ** np.minimum(x / period, float(doublings))).astype(np.uint32)
+
+
+@pytest.mark.parametrize("kind,skew", [("lognormal", 0), ("lognormal", 3), ("ramp", 0)])
+def test_em_blocks_ahead_at_w12_against_the_oracle_on_tables_that_cross_many_binades(ctx, kind, skew):
+    """The blocks-ahead EM at W = 12 (1024 blocks per cell, 16 chunks of block records per chain) against the ORACLE's
+    left-to-right float32 sums, bit for bit -- not against this library's own dependent-addition fold -- on tables whose
+    sums cross many binades: heavy-tailed lognormal counts, and a ramp that doubles the running sum every 16 blocks.
+    (Reference: /root/reference/src/peng.cpp:104-144.)"""
+    W = 12
+    NP = 4 ** W
+    rng = np.random.default_rng(1200 + skew)
+    c = rng.lognormal(1.0, 2.5, NP).astype(np.uint32) if kind == "lognormal" else _ramp_counts(W)
+    bg = (rng.dirichlet(np.ones(64), size=NP // 64).reshape(-1)).astype(np.float32)
+    pwms = np.maximum(rng.dirichlet(np.full(4, 0.5 if kind == "lognormal" else 40.0), size=(3, W)).astype(np.float32), np.float32(1e-20))
+    counts, bgd = pk.DeviceArray.from_host(ctx, c), pk.DeviceArray.from_host(ctx, bg)
+    ctx.set_option("em_fast", 2)
+    try:
+        ctx.set_option("em_test_skew", skew)
+        got, iters, change = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 2)
+        met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks", "restaged_blocks", "restaged_waits")}
+    finally:
+        ctx.set_option("em_test_skew", 0)
+        ctx.set_option("em_fast", 1)
+    c64 = c.astype(np.uint64)
+    for i in range(len(pwms)):
+        ref, it, ch = po.em(W, c64, bg, pwms[i], 1e4, 0.0, 2, mode=0, final_norm=False)
+        assert iters[i] == it == 2
+        assert got[i].tobytes() == ref.astype(np.float32).tobytes(), (kind, skew, i)
+        assert np.float32(change[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
+    chains = len(pwms) * 4 * W * 2
+    assert met["fetched_blocks"] >= chains, met  # at least block 0 of every chain (the sum climbs from zero there)
+    if kind == "ramp":
+        assert met["fetched_blocks"] > 10 * chains, met  # ~30 crossings per chain
+    if skew:
+        assert met["mispredicted_blocks"] > 0 and met["restaged_blocks"] > 0, met
+
+
+def test_em_chain_walk_restaged_block_is_pinned(ctx):
+    """The defect round 3's soak found once in ~2000 random W = 12 cases, walked on purpose (csrc/seqsum.h, walk_chain):
+    a chunk of 64 block records holds blocks A < B without a binade -- both asked for when the chunk starts, A into
+    buffer a, B into buffer b -- and, in FRONT of A, a block M whose binade does not hold.  M is fetched on demand
+    through buffer a; A is asked for again and its loads are now YOUNGER than B's, so the wait in front of A's rows must
+    be vmcnt(0): the counted vmcnt(16), right for the usual order, covers B only, and the wave would read M's rows as
+    A's.  The ramp table puts ~4 blocks without a binade into most chunks of a chain's first half, em_test_skew = 3
+    makes every third block a wrong guess: `restaged_waits` counts the takes of a re-requested block with another block
+    staged behind it, and the PWMs must be the oracle's bit for bit.  (A build with -DPENGK_TEST_WALK_RACE puts the
+    counted wait back: this test fails on it, profiles/r04_walk_race_pin.log.)"""
+    W = 12
+    c = _ramp_counts(W)
+    rng = np.random.default_rng(77)
+    bg = np.full(4 ** W, np.float32(1.0 / 4 ** W))
+    pwms = rng.dirichlet(np.full(4, 60.0), size=(4, W)).astype(np.float32)
+    counts, bgd = pk.DeviceArray.from_host(ctx, c), pk.DeviceArray.from_host(ctx, bg)
+    ctx.set_option("em_fast", 2)
+    try:
+        ctx.set_option("em_test_skew", 3)
+        got, iters, change = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 2)
+        met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks", "restaged_blocks", "restaged_waits")}
+    finally:
+        ctx.set_option("em_test_skew", 0)
+        ctx.set_option("em_fast", 1)
+    assert met["restaged_waits"] >= 4 * 4 * W, met  # at least once per chain on average (first iteration alone)
+    c64 = c.astype(np.uint64)
+    for i in range(len(pwms)):
+        ref, it, ch = po.em(W, c64, bg, pwms[i], 1e4, 0.0, 2, mode=0, final_norm=False)
+        assert iters[i] == it == 2
+        assert got[i].tobytes() == ref.astype(np.float32).tobytes(), i
+        assert np.float32(change[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
 
 
 def test_em_serial_batches_on_several_streams(ctx, golden_dir):

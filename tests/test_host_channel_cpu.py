@@ -124,3 +124,45 @@ def test_a_rank_that_dies_fails_its_peers():
     assert res[1][0] == 0
     assert res[0][0] == 4 and "GATHER_FAILED" in res[0][1] and "did not answer" in res[0][1], res[0]
     assert time.time() - t0 < 60
+
+
+def test_silent_connections_do_not_hold_up_the_ranks():
+    """Introductions are read without blocking: six connections that never say a word (each used to cost the accept loop a
+    5 s blocking read, one after the other) leave the rendezvous of the real ranks where it was."""
+    port = free_port()
+    p0 = start(0, 2, port, timeout_s=60)
+    strays = []
+    deadline = time.time() + 30
+    while time.time() < deadline and len(strays) < 6:
+        try:
+            strays.append(socket.create_connection(("127.0.0.1", port), timeout=1))
+        except OSError:
+            time.sleep(0.05)
+    assert len(strays) == 6
+    t0 = time.time()
+    p1 = start(1, 2, port, timeout_s=60)
+    res = finish([p0, p1])
+    took = time.time() - t0
+    assert [r[0] for r in res] == [0, 0], res
+    assert took < 15, took  # process start + collectives; 30 s and more with serial blocking reads
+    for s in strays:
+        s.close()
+
+
+def test_rank0_listens_on_all_interfaces_only_with_a_job_secret():
+    """MASTER_ADDR that is not an address of this host (192.0.2.1, TEST-NET-1): without PENGK_COMM_TOKEN rank 0 refuses
+    (the derived token is computable from public launcher values and authenticates nobody); with a secret it falls
+    back to all interfaces and then waits for its peers as usual."""
+    def rank0(token):
+        env = dict(os.environ, RANK="0", WORLD_SIZE="2", MASTER_ADDR="192.0.2.1", MASTER_PORT="29999", PENGK_COMM_PORT=str(free_port()),
+                   PENGK_COMM_TIMEOUT="2")
+        env.pop("PENGK_COMM_TOKEN", None)
+        if token:
+            env["PENGK_COMM_TOKEN"] = token
+        p = subprocess.Popen([sys.executable, "-c", WORKER, "run"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        (rc, so, se), = finish([p])
+        return rc, so
+    rc, so = rank0(None)
+    assert rc == 3 and "not an address of this host" in so, so
+    rc, so = rank0("a job secret")
+    assert rc == 3 and "only 1 of 2 ranks" in so, so
