@@ -368,6 +368,11 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
+    # ---- end to end, first: the peng_motif CLI on the config's FASTA, before this process touches the GPU -------------
+    e2e_state = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("PENGK_BENCH_FORCE_COMM") and not args.no_e2e:
+        e2e_state = e2e_cli(args, args.W, args.strand == "BOTH", args.L, args.nseq)
+
     # stdout carries the ONE JSON line and nothing else: librccl announces its version there while communicators are
     # built (torch's and libpengk's), so file descriptor 1 points at stderr for the rest of the run and the line goes to
     # a duplicate of the original
@@ -668,8 +673,8 @@ def main():
         torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, W, both, L, stress_probe)
-        if world == 1 and not args.no_e2e:
-            out["components"]["e2e_cli"] = e2e_cli(args, W, both, L, nseq, out.get("cpu_baseline"))
+        if e2e_state is not None:
+            out["components"]["e2e_cli"] = e2e_reference(e2e_state[0], e2e_state[1], args, W, both, L, nseq, out.get("cpu_baseline"))
             ref_full = out["components"]["e2e_cli"].get("reference_same_box")
             if ref_full is not None and "cpu_baseline" in out:
                 out["cpu_baseline"]["reference_full_size"] = ref_full
@@ -733,23 +738,28 @@ def reference_same_box(fa, tmp, W, both, L, nseq, our_wall, cpu_base, our_best=N
             "command": "oracle/_ref/peng_motif_ref s.fa -w %d --strand %s --threads 1 -o ref.meme (same file, same box, same run)" % (W, "BOTH" if both else "PLUS")}
 
 
-def e2e_cli(args, W, both, L, nseq, cpu_base=None):
+def e2e_cli(args, W, both, L, nseq):
     """End to end: the config's FASTA on disk -> peng-motif_amd/host/peng_motif (PENGK_TIMING=1) -> MEME + JSON, wall clock
-    of the process and the phases it reports; then the compiled reference on the same file on this box
-    (reference_same_box).  BASELINE.md's 277.3 s (10M x 200 bp, W=10, 1 thread) was measured in the survey container, on
-    another machine: it is kept as context and labelled so."""
+    of the process and the phases it reports, `--e2e-runs` times.  Runs FIRST, before this process has touched the GPU:
+    the program is timed the way a user starts it, not beside a parent that holds a HIP context of its own (measured: the
+    child's runtime start and exit take ~0.2 s longer then).  Returns (result, scratch directory); the directory keeps
+    the FASTA and the MEME file for e2e_reference, which runs the compiled reference on the same file at the end.
+    BASELINE.md's 277.3 s (10M x 200 bp, W=10, 1 thread) was measured in the survey container, on another machine: it is
+    kept as context and labelled so."""
     exe = os.path.join(ROOT, "peng-motif_amd", "host", "peng_motif")
     gen = os.path.join(ROOT, "tools", "synth_fasta")
     if not (os.path.exists(exe) and os.path.exists(gen)):
-        return {"error": "peng_motif / synth_fasta not built"}
+        return {"error": "peng_motif / synth_fasta not built"}, None
+    import atexit
     import shutil
     import tempfile
     base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 4 * nseq * (L + 12) else None
     tmp = tempfile.mkdtemp(prefix="pengk_e2e_", dir=base)
-    try:
+    atexit.register(shutil.rmtree, tmp, ignore_errors=True)
+    if True:  # (the scratch directory outlives this function: e2e_reference / atexit remove it)
         fa = os.path.join(tmp, "s.fa")
         t0 = time.perf_counter()
-        subprocess.run([gen, fa, str(nseq), str(L), "1", "0"], check=True, timeout=600)
+        subprocess.run([gen, fa, str(nseq), str(L), "1", "0"], check=True, timeout=600, stdout=subprocess.DEVNULL)
         t_gen = time.perf_counter() - t0
         cmd = [exe, fa, "-w", str(W), "--strand", "BOTH" if both else "PLUS", "-o", os.path.join(tmp, "o.meme"), "-j",
                os.path.join(tmp, "o.json")]
@@ -773,7 +783,7 @@ def e2e_cli(args, W, both, L, nseq, cpu_base=None):
             rc = p.wait(timeout=900)
             wall = time.perf_counter() - t0
             if rc != 0:
-                return {"error": "peng_motif exited %d: %s" % (rc, "\n".join(tail)[-300:])}
+                return {"error": "peng_motif exited %d: %s" % (rc, "\n".join(tail)[-300:])}, None
             runs.append({"wall_s": round(wall, 3), "phases_s": phases, "runtime_start_ms": create,
                          # from the program's own "[timing] total" line to the process being gone (what the caller still waits for)
                          "exit_s": round(wall - t_total_line, 3) if t_total_line is not None else None,
@@ -792,11 +802,21 @@ def e2e_cli(args, W, both, L, nseq, cpu_base=None):
                # context only: a different machine (the survey container), NOT a same-box ratio
                "reference_wall_s_baseline_md_other_machine": 277.3 if is_c2 else None,
                "cross_machine_ratio_vs_baseline_md": round(277.3 / median, 1) if is_c2 else None}
-        if not args.no_cpu_baseline:
-            res["reference_same_box"] = reference_same_box(fa, tmp, W, both, L, nseq, median, cpu_base, walls[0])
-        return res
+        res["measured"] = "before this process touched the GPU (first leg of the run)"
+        return res, tmp
+
+
+def e2e_reference(res, tmp, args, W, both, L, nseq, cpu_base):
+    """The compiled reference on the file e2e_cli timed peng_motif on, same box, same run (reference_same_box)."""
+    import shutil
+    try:
+        if tmp and "error" not in res and not args.no_cpu_baseline:
+            res["reference_same_box"] = reference_same_box(os.path.join(tmp, "s.fa"), tmp, W, both, L, nseq, res["wall_s"], cpu_base,
+                                                           res["best_wall_s"])
     finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        if tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return res
 
 
 def cpu_baseline(args, W, both, L, stress_probe=None):

@@ -23,7 +23,7 @@ FRONT_PAD_BASES = 64
 EXPORTS = [
     "pengk_version", "pengk_last_error", "pengk_error_name", "pengk_create", "pengk_destroy", "pengk_synchronize",
     "pengk_stream", "pengk_set_stream", "pengk_set_option", "pengk_get_info", "pengk_malloc", "pengk_free", "pengk_memcpy_h2d", "pengk_memcpy_d2h",
-    "pengk_memset", "pengk_host_alloc", "pengk_host_free", "pengk_timer_create", "pengk_timer_record", "pengk_timer_elapsed_ms", "pengk_timer_destroy",
+    "pengk_memset", "pengk_warmup", "pengk_host_alloc", "pengk_host_free", "pengk_timer_create", "pengk_timer_record", "pengk_timer_elapsed_ms", "pengk_timer_destroy",
     "pengk_pack", "pengk_pack_threads", "pengk_pack_append", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
     "pengk_count", "pengk_count_bg", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
     "pengk_seed_candidates", "pengk_iupac_aggregate", "pengk_em", "pengk_em_device", "pengk_sequential_sum_f32", "pengk_motif_similarity",
@@ -76,6 +76,7 @@ def lib():
         L.pengk_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
         L.pengk_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
         L.pengk_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
+        L.pengk_warmup.argtypes = [vp]
         L.pengk_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.pengk_host_free.argtypes = [vp, vp]
         L.pengk_timer_create.argtypes = [vp, C.POINTER(vp)]

@@ -43,6 +43,14 @@ int enter(pengk_ctx* ctx) {
   return PENGK_OK;
 }
 
+static int warm_code_objects() {
+  int rc = warm_stats();
+  if (!rc) rc = warm_iupac();
+  if (!rc) rc = warm_em();
+  if (!rc) rc = warm_similarity();
+  return rc;
+}
+
 }  // namespace pengk
 
 using namespace pengk;
@@ -291,6 +299,30 @@ int pengk_memcpy_h2d(pengk_ctx* ctx, void* d_dst, const void* h_src, size_t byte
   PENGK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   PENGK_HIP(hipStreamSynchronize(ctx->stream));
   return PENGK_OK;
+}
+
+// First uses cost: the first device-to-host copy of a process takes 10-17 ms whatever its size (the copy path of that
+// direction is set up then), and every translation unit's code object is loaded at the first launch of one of its
+// kernels.  A host that has something else to do meanwhile (the CLI: the upload of the packed sequences) calls this
+// once, from any thread, right after pengk_create; nothing depends on it.
+int pengk_warmup(pengk_ctx* ctx) {
+  if (!ctx) return fail(PENGK_ERR_ARG, "ctx is NULL");
+  PENGK_ENTER(ctx);
+  // (on the context's own stream: a new stream is a new hardware queue, 20-40 ms on this host -- which is also why a
+  // large upload split over several threads and streams, 22 instead of 35 ms in tools/ubench/runtime_start2.cpp, LOST in
+  // the CLI: 120 ms instead of 18, profiles/r04_e2e_experiments.log)
+  // (a copy of the size of a result table into page-locked memory: a few bytes do not take the path the tables take)
+  constexpr size_t N = (size_t)4 << 20;
+  void* d = nullptr;
+  void* h = nullptr;
+  hipError_t e = hipMalloc(&d, N);
+  if (e == hipSuccess) e = hipHostMalloc(&h, N, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, N, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (h) (void)hipHostFree(h);
+  if (d) (void)hipFree(d);
+  if (e != hipSuccess) return hip_fail(e, "pengk_warmup");
+  return warm_code_objects();
 }
 
 int pengk_memcpy_d2h(pengk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {

@@ -1393,4 +1393,11 @@ int launch_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturat
   }
 }
 
+// (pengk_warmup: loads this translation unit's code object ahead of its first launch)
+int warm_em() {
+  hipFuncAttributes a;
+  PENGK_HIP(hipFuncGetAttributes(&a, (const void*)em_init_kernel));
+  return PENGK_OK;
+}
+
 }  // namespace pengk

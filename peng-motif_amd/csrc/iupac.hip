@@ -425,4 +425,11 @@ int launch_iupac(pengk_ctx* ctx, int W, int both, const uint64_t* h_ids, int64_t
   return PENGK_OK;
 }
 
+// (pengk_warmup: loads this translation unit's code object ahead of its first launch)
+int warm_iupac() {
+  hipFuncAttributes a;
+  PENGK_HIP(hipFuncGetAttributes(&a, (const void*)iupac_block_kernel));
+  return PENGK_OK;
+}
+
 }  // namespace pengk

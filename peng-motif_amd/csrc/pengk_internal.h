@@ -68,6 +68,10 @@ int hip_fail(hipError_t e, const char* what);
 int ensure_scratch(pengk_ctx* ctx, void** slot, size_t* have, size_t need);
 int enter(pengk_ctx* ctx);      // hipSetDevice(ctx->device)
 int count_init_device();        // per-device kernel attributes of count.hip (current device)
+int warm_stats();
+int warm_iupac();
+int warm_similarity();
+int warm_em();  // (one kernel of each translation unit: its code object is loaded)
 void comm_release(pengk_ctx* ctx);  // destroys the RCCL communicator, if any
 
 #define PENGK_HIP(call)                                   \

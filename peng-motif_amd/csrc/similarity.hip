@@ -120,4 +120,11 @@ int launch_similarity(pengk_ctx* ctx, int n, const float* d_pwm, const float* d_
   return PENGK_OK;
 }
 
+// (pengk_warmup: loads this translation unit's code object ahead of its first launch)
+int warm_similarity() {
+  hipFuncAttributes a;
+  PENGK_HIP(hipFuncGetAttributes(&a, (const void*)similarity_kernel));
+  return PENGK_OK;
+}
+
 }  // namespace pengk

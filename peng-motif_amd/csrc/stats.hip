@@ -160,4 +160,11 @@ int launch_stats(pengk_ctx* ctx, int W, int both, int k, int max_k, const float*
   }
 }
 
+// (pengk_warmup: loads this translation unit's code object ahead of its first launch)
+int warm_stats() {
+  hipFuncAttributes a;
+  PENGK_HIP(hipFuncGetAttributes(&a, (const void*)seed_candidates_kernel));
+  return PENGK_OK;
+}
+
 }  // namespace pengk

@@ -4,6 +4,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <mutex>
@@ -67,12 +68,20 @@ void check(int rc, const char* what) {
 }
 
 // Context creation (HIP runtime start-up + code object load, ~0.2 s) can run beside the FASTA reader.
-static std::thread g_starter;
+static std::thread g_starter, g_warmer;
 static int g_starter_rc = PENGK_OK;
 
 static void join_starter() {
   if (g_starter.joinable()) g_starter.join();
+  if (g_warmer.joinable()) g_warmer.join();
 }
+
+// seconds since the process image started (PENGK_TIMING: when did the context come up, when was the upload done)
+static double since_start() {
+  static const auto t0 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+static const double g_clock_anchor = since_start();
 
 void start_context() {
   if (g_ctx || g_starter.joinable()) return;
@@ -83,6 +92,10 @@ void start_context() {
       std::cerr << "Error: pengk_create failed: " << pengk_error_name(g_starter_rc) << ": " << pengk_last_error() << std::endl;
       _exit(1);
     }
+    if (std::getenv("PENGK_TIMING")) std::cerr << "[timing] (device context up at " << since_start() << " s)" << std::endl;
+    // first-use costs that nothing has to wait for (the first device-to-host copy of a process: 10-17 ms; the code objects
+    // of the sweep / IUPAC / EM kernels) are paid beside the upload of the packed sequences
+    if (!std::getenv("PENGK_NO_WARMUP")) g_warmer = std::thread([] { (void)pengk_warmup(g_ctx); });
   });
   atexit(join_starter);  // an exit() on a FASTA error must not tear the process down under a starting runtime
 }
@@ -218,6 +231,7 @@ void upload_loop(Stream* st) {
   }
   st->in.n_words = sent;
   st->in.n_items = n_items;
+  if (std::getenv("PENGK_TIMING")) std::cerr << "[timing] (packed sequences on the device at " << since_start() << " s)" << std::endl;
 }
 
 void sink_begin(void* user, size_t range_bytes, size_t n_chunks) {
@@ -289,6 +303,7 @@ void begin_streaming_pack(int W) {
 const PackedInput* finish_streaming_pack(SequenceSet* set) {
   Stream* st = g_stream;
   if (!st) return nullptr;
+  if (std::getenv("PENGK_TIMING")) std::cerr << "[timing] (reader done at " << since_start() << " s)" << std::endl;
   if (st->started) {
     {
       std::lock_guard<std::mutex> lock(st->mu);
@@ -302,10 +317,11 @@ const PackedInput* finish_streaming_pack(SequenceSet* set) {
     exit(1);
   }
   st->set = set;
-  // the host copies have done their duty
-  if (st->target.words) munmap(st->target.words, st->words_bytes);
-  if (st->target.items) munmap(st->target.items, st->items_bytes);
-  st->target.words = st->target.items = nullptr;
+  // The host copies have done their duty, but they are NOT handed back here: with the reader's threads just gone, an
+  // munmap of 0.6 GB costs ~35 ms of TLB shoot-downs on the bench's input -- on this thread, or, from a helper thread, as
+  // 33 ms of a blocked pengk_set_sequences -- while the exiting process returns the same pages for nothing
+  // (tools/e2e_ab.sh, profiles/r04_e2e_experiments.log: median 0.45 / 0.43 / 0.32 s with sync / async / no release on a
+  // noisy box).  ~Stream (PENGK_FULL_TEARDOWN) releases them.
   if (!st->in.d_words) return nullptr;  // no records at all on this rank: the staged path handles the empty shard
   return &st->in;
 }
