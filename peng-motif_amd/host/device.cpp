@@ -332,6 +332,7 @@ const PackedInput* packed_input(SequenceSet* set, int W) {
 }
 
 void shutdown() {
+  join_starter();  // (the warm-up thread reads the context: found by tests/tools/tsan_host.sh)
   Lap lap("  ");
   if (g_stream && g_ctx) {
     if (g_stream->in.d_words) pengk_free(g_ctx, g_stream->in.d_words);
