@@ -295,6 +295,13 @@ int pengk_sequential_sum_f32(pengk_ctx* ctx, const float* d_terms, uint64_t n_ch
 int pengk_motif_similarity(pengk_ctx* ctx, int n, const float* h_pwm, const float* h_comp, const int32_t* h_len,
                            const uint64_t* h_sites, int both_strands, const float* h_bg, int first_new, float* h_out);
 
+/* Self-test of the division sequence the serial EM's weights kernel uses where a PWM's operand ranges allow (the IEEE
+ * division's instructions without its range scaling: csrc/em.hip, lean_div; src/peng.cpp:124-125, 186 are the three
+ * divisions of a weight).  4096 x 256 threads draw pairs_per_thread random operand pairs each, keep those inside the
+ * guard's domain and compare with the compiler's division bit for bit.  h_out[0] = pairs compared, [1] = pairs that
+ * differ (must be 0), [2] = of the compared: pairs with a numerator of zero. */
+int pengk_selftest_division(pengk_ctx* ctx, uint64_t seed, uint32_t pairs_per_thread, uint64_t* h_out /* [3] */);
+
 /* ---- C1: the one exchange step of a multi-GPU run (no counterpart in the reference, which is a single
  *      process).  One process per GPU; sequences shard by whole records; every rank counts its shard, then the
  *      count table, ltot and the 84 background counters are summed over the ranks -- exact, because the non-overlap

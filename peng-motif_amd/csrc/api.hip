@@ -187,6 +187,10 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     ctx->em_test_skew = (int)value;
     return PENGK_OK;
   }
+  if (strcmp(name, "em_lean_div") == 0) {
+    ctx->em_lean_div = value != 0;
+    return PENGK_OK;
+  }
   if (strcmp(name, "em_overlap") == 0) {
     if (value < 1 || value > MAX_EM_LANES) return fail(PENGK_ERR_ARG, "em_overlap must be 1 .. %d streams", MAX_EM_LANES);
     ctx->em_overlap = (int)value;

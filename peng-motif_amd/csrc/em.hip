@@ -16,6 +16,7 @@
 // here they are accumulated in fp64 through a fixed tree (thread -> wave -> block -> grid), so the
 // result is deterministic and within 1 ulp(float) of the exact sum.
 #include <algorithm>
+#include <type_traits>
 
 #include "pengk_internal.h"
 #include "seqsum.h"
@@ -768,6 +769,140 @@ __device__ __forceinline__ uint32_t block_binade(double before, double after, ui
   return e;
 }
 
+// ---- the three IEEE divisions of a weight, without the range scaling when it cannot matter ---------------------------
+// `a / b` in float compiles to v_div_scale x 2, v_rcp, five fma / mul, v_div_fmas, v_div_fixup (11 instructions, the
+// reciprocal at quarter rate): 33 of the ~47 vector instructions of a weight.  v_div_scale returns its operand unchanged
+// and VCC = 0 -- so that v_div_fmas is a plain fma -- and v_div_fixup passes the quotient through, when (gfx9 ISA,
+// V_DIV_SCALE_F32 / V_DIV_FIXUP_F32): numerator and denominator are finite, the denominator is normal and below 2^126,
+// the numerator's biased exponent is above 23 (or the numerator is zero: every product below is then zero, and so is the
+// fixup's answer), the exponents differ by less than 96 and the quotient is normal.  Then the eight instructions in
+// between ARE the division, bit for bit: the same v_rcp_f32, the same fmas in the same order.  lean_div issues exactly
+// those.  Whether a workgroup may use it is decided once per workgroup from the RANGES its operands can take --
+// the PWM's columns give the range of the product, em_bg_range_kernel the range of the background table, the count
+// table's 32 bits the range of c * s -- with a factor of two of slack on every derived bound (lean_ranges_ok);
+// a workgroup whose ranges do not qualify (tiny PWM entries, a degenerate background) runs the plain divisions.
+__device__ __forceinline__ float lean_div(float a, float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  const float e0 = __builtin_fmaf(-b, y0, 1.0f);
+  const float y1 = __builtin_fmaf(e0, y0, y0);
+  const float q0 = a * y1;
+  const float r0 = __builtin_fmaf(-b, q0, a);
+  const float q1 = __builtin_fmaf(r0, y1, q0);
+  const float r1 = __builtin_fmaf(-b, q1, a);
+  return __builtin_fmaf(r1, y1, q1);
+}
+template <bool LEAN>
+__device__ __forceinline__ float em_div(float a, float b) {
+  if constexpr (LEAN) return lean_div(a, b);
+  else return a / b;
+}
+// a / b for every a in [a_lo, a_hi] (or a == 0) and b in [b_lo, b_hi], all bounds positive: is the unscaled sequence the
+// division?  (biased exponents; the quotient of a and b lies in [2^(Ea - Eb - 1), 2^(Ea - Eb + 1)))
+__device__ __forceinline__ bool lean_div_ok(float a_lo, float a_hi, float b_lo, float b_hi) {
+  auto fin = [](float x) { return __float_as_uint(x) - 0x00800000u < 0x7F000000u; };  // normal, finite, positive
+  if (!(fin(a_lo) && fin(a_hi) && fin(b_lo) && fin(b_hi)) || a_lo > a_hi || b_lo > b_hi) return false;
+  const int ea_lo = (int)(__float_as_uint(a_lo) >> 23), ea_hi = (int)(__float_as_uint(a_hi) >> 23);
+  const int eb_lo = (int)(__float_as_uint(b_lo) >> 23), eb_hi = (int)(__float_as_uint(b_hi) >> 23);
+  return eb_hi <= 251 && ea_lo >= 25 && ea_hi - eb_lo <= 94 && ea_lo - eb_hi >= -123;
+}
+// The ranges of one PWM's three divisions (src/peng.cpp:124-125, 180-197): odds = pr / bg, t = s / odds,
+// w = (c s) / (1 + t).  bg_range = {min, max} of the background table as float bits (em_bg_range_kernel).
+template <int W>
+__device__ __forceinline__ bool lean_ranges_ok(const float* s_pwm, const uint32_t* bg_range, float saturation) {
+  float p_lo = 1.0f, p_hi = 1.0f;
+  for (int p = 0; p < W; ++p) {
+    const float a = s_pwm[p * 4], b = s_pwm[p * 4 + 1], c = s_pwm[p * 4 + 2], d = s_pwm[p * 4 + 3];
+    if (!(a > 0.0f && b > 0.0f && c > 0.0f && d > 0.0f)) return false;
+    p_lo *= fminf(fminf(a, b), fminf(c, d));
+    p_hi *= fmaxf(fmaxf(a, b), fmaxf(c, d));
+  }
+  // (products round: half a unit in the last place per factor, far inside the factor of two below)
+  p_lo *= 0.5f;
+  p_hi *= 2.0f;
+  const float b_lo = __uint_as_float(bg_range[0]), b_hi = __uint_as_float(bg_range[1]);
+  if (bg_range[1] > 0x7F7FFFFFu || !(saturation > 0.0f)) return false;  // a negative or non-finite background entry
+  if (!lean_div_ok(p_lo, p_hi, b_lo, b_hi)) return false;
+  const float o_lo = p_lo / b_hi * 0.5f, o_hi = p_hi / b_lo * 2.0f;  // odds
+  if (!lean_div_ok(saturation, saturation, o_lo, o_hi)) return false;
+  const float t_hi = saturation / o_lo * 2.0f;  // s / odds <= t_hi; 1 + t in [1, 2 (1 + t_hi)]
+  const float n_lo = saturation * 0.5f, n_hi = saturation * 8589934592.0f;  // c s, c in [1, 2^32): [s / 2, 2^33 s]
+  return lean_div_ok(n_lo, n_hi, 1.0f, (1.0f + t_hi) * 2.0f);
+}
+
+// {min, max} of the background table as float bits (non-negative floats order like their bits; a negative entry or a NaN
+// has the sign or all exponent bits set and ends up as a "max" no range test accepts).  Once per pengk_em call.
+__global__ __launch_bounds__(1024) void em_bg_range_kernel(const float* __restrict__ bg, uint32_t np, uint32_t* __restrict__ range) {
+  // (32 workgroups, one pair of atomics each: same-address device atomics queue up at ~20 ns apiece -- with one pair per
+  // wave of a 256 x 256 grid this kernel took 29 us, six times the weights' saving per iteration)
+  __shared__ uint32_t s_lo[16], s_hi[16];
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+  const uint4* v = reinterpret_cast<const uint4*>(bg);
+  for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < np / 4u; i += gridDim.x * 1024u) {
+    const uint4 b = v[i];
+    lo = min(min(lo, b.x), min(min(b.y, b.z), b.w));
+    hi = max(max(hi, b.x), max(max(b.y, b.z), b.w));
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, m, 64));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, m, 64));
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) {
+      lo = min(lo, s_lo[w]);
+      hi = max(hi, s_hi[w]);
+    }
+    atomicMin(range, lo);
+    atomicMax(range + 1, hi);
+  }
+}
+
+// Self-test of lean_div (pengk_selftest_division): random operand pairs inside lean_div_ok's domain -- exponents over the
+// whole range the guard admits, random mantissas, and the special mantissas (all zeros / all ones / one bit) where a
+// division is likeliest to round the other way -- the unscaled sequence against the compiler's IEEE division.
+__global__ __launch_bounds__(256) void em_div_check_kernel(unsigned long long seed, uint32_t per_thread, unsigned long long* __restrict__ out) {
+  unsigned long long st = seed + 0x9E3779B97F4A7C15ull * (blockIdx.x * 256ull + threadIdx.x + 1ull);
+  auto next = [&]() {
+    unsigned long long z = (st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  unsigned long long checked = 0, bad = 0, zero = 0;
+  for (uint32_t i = 0; i < per_thread; ++i) {
+    const unsigned long long r = next(), q = next();
+    uint32_t ma = (uint32_t)r & 0x7FFFFFu, mb = (uint32_t)(r >> 23) & 0x7FFFFFu;
+    const uint32_t kind = (uint32_t)(q >> 60);
+    if (kind == 0u) ma = 0u;
+    else if (kind == 1u) mb = 0u;
+    else if (kind == 2u) ma = 0x7FFFFFu;
+    else if (kind == 3u) mb = 0x7FFFFFu;
+    else if (kind == 4u) mb = 1u << ((q >> 40) % 23u);
+    const uint32_t ea = 1u + (uint32_t)(q % 254ull), eb = 1u + (uint32_t)((q >> 8) % 254ull);
+    float a = __uint_as_float((ea << 23) | ma);
+    const float b = __uint_as_float((eb << 23) | mb);
+    if (!lean_div_ok(a, a, b, b)) continue;
+    if (((q >> 50) & 63ull) == 0ull) {  // a numerator of zero (a count of zero) is part of the domain
+      a = 0.0f;
+      ++zero;
+    }
+    const float lean = lean_div(a, b);
+    float full;
+    asm volatile("" : "+v"(a));  // (the two divisions are not to be merged)
+    full = a / b;
+    ++checked;
+    bad += __float_as_uint(lean) != __float_as_uint(full);
+  }
+  atomicAdd(out, checked);
+  atomicAdd(out + 1, bad);
+  atomicAdd(out + 2, zero);
+}
+
 // The weights of a span, as em_weights_kernel computes them, and on the way the span's block sums.  A workgroup per span:
 // thread t = digits 0..3 of x (lane = digits 0..2: a wave stores 64 consecutive floats), 64 x per thread over digits 4..6.
 // The product over the PWM columns in the reference's order ((1*pwm[0][x0])*pwm[1][x1])... (src/peng.cpp:180-197): the
@@ -777,15 +912,19 @@ template <int W>
 __global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
                                                               const uint32_t* __restrict__ counts, const float* __restrict__ bg,
                                                               float saturation, float* __restrict__ wbuf, uint32_t* __restrict__ bad,
-                                                              float* __restrict__ sums) {
+                                                              float* __restrict__ sums, const uint32_t* __restrict__ bg_range) {
   using G = BlockGeo<W>;
   const uint32_t pw = blockIdx.y, sp = blockIdx.x;
   if (state[2 * pw + 1] == 0) return;
   __shared__ float s_pwm[W * 4];
   __shared__ float part[4][28];
+  __shared__ uint32_t s_lean;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   if (t < W * 4) s_pwm[t] = pwms[(size_t)pw * W * 4 + t];
   __syncthreads();
+  if (t == 0) s_lean = lean_ranges_ok<W>(s_pwm, bg_range, saturation) ? 1u : 0u;  // (workgroup-uniform: one PWM, one table)
+  __syncthreads();
+  const bool lean = s_lean != 0u;
   float* out = wbuf + (size_t)pw * G::NP + (size_t)sp * 16384u;
   const uint32_t* cnt = counts + (size_t)sp * 16384u;
   const float* bgs = bg + (size_t)sp * 16384u;
@@ -804,28 +943,33 @@ __global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __res
   }
   float c4[4] = {0, 0, 0, 0}, c5[4] = {0, 0, 0, 0}, c6[4] = {0, 0, 0, 0};
   bool flagged = false;
+  auto body = [&](auto lean_tag) {
+    constexpr bool LEAN = decltype(lean_tag)::value;
 #pragma unroll 1
-  for (uint32_t d6 = 0; d6 < 4u; ++d6) {
+    for (uint32_t d6 = 0; d6 < 4u; ++d6) {
 #pragma unroll
-    for (uint32_t d5 = 0; d5 < 4u; ++d5) {
-      float s5 = 0.0f;
+      for (uint32_t d5 = 0; d5 < 4u; ++d5) {
+        float s5 = 0.0f;
 #pragma unroll
-      for (uint32_t d4 = 0; d4 < 4u; ++d4) {
-        const uint32_t xl = t + 256u * (d4 + 4u * d5 + 16u * d6);
-        float pr = ((p3 * f4_[d4]) * f5_[d5]) * f6_[d6];
+        for (uint32_t d4 = 0; d4 < 4u; ++d4) {
+          const uint32_t xl = t + 256u * (d4 + 4u * d5 + 16u * d6);
+          float pr = ((p3 * f4_[d4]) * f5_[d5]) * f6_[d6];
 #pragma unroll
-        for (int p = 7; p < W; ++p) pr = pr * hi[p - 7];
-        const float odds = pr / bgs[xl];
-        const float v = ((float)cnt[xl] * saturation) / (1 + saturation / odds);  // :124-125
-        out[xl] = v;
-        flagged |= __float_as_uint(v) > 0x7F7FFFFFu;
-        c4[d4] += v;
-        s5 += v;
+          for (int p = 7; p < W; ++p) pr = pr * hi[p - 7];
+          const float odds = em_div<LEAN>(pr, bgs[xl]);
+          const float v = em_div<LEAN>((float)cnt[xl] * saturation, 1 + em_div<LEAN>(saturation, odds));  // :124-125
+          out[xl] = v;
+          flagged |= __float_as_uint(v) > 0x7F7FFFFFu;
+          c4[d4] += v;
+          s5 += v;
+        }
+        c5[d5] += s5;
+        c6[d6] += s5;
       }
-      c5[d5] += s5;
-      c6[d6] += s5;
     }
-  }
+  };
+  if (lean) body(std::true_type{});
+  else body(std::false_type{});
   if (flagged) bad[pw] = 1u;  // (as em_weights_kernel: this PWM's cells are summed by the finalize kernel's plain loop)
   const float tot = (c6[0] + c6[1]) + (c6[2] + c6[3]);
   // per wave: whole-wave sums by digit 4, 5, 6; the total by digit 0, 1, 2 (lane bits 0-1, 2-3, 4-5); the total (digit 3)
@@ -973,16 +1117,56 @@ template <int W>
 __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
                                                                             seqsum::BlockRecord* __restrict__ rec,
                                                                             const uint32_t* __restrict__ bad, uint32_t n_pwm,
-                                                                            const float* __restrict__ sums, uint32_t skew) {
+                                                                            const float* __restrict__ sums, uint32_t skew,
+                                                                            uint32_t extra_wgs) {
   using G = BlockGeo<W>;
   // (consecutive workgroups go to consecutive XCDs: a PWM's spans, and behind them its chains, stay on one -- as in
   // em_fold_scan_kernel; 1000 PWMs x 10 iterations: 35.5 ms, with PWM = blockIdx.y 37.5)
-  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
-  const uint32_t pw = (lin & 7u) + 8u * (slot / G::SPANS), sp = slot % G::SPANS;
-  if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
+  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
   __shared__ __attribute__((aligned(16))) float span[16384];
   const uint32_t t = threadIdx.x, lane = t & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+  if (lin < extra_wgs) {
+    // The workgroups IN FRONT of the spans' (they start first; behind them they were the kernel's tail: 29 -> 36 us) fold
+    // BLOCK 0 of every cell: its start is known exactly (zero), and it is the
+    // dearest block of a chain -- the sum climbs through some twenty binades in it, each crossing another evaluation --
+    // so it is folded here, beside the evaluation of all the other blocks, instead of at the head of every chain
+    // (em_chain_kernel: 37 -> 30 us per iteration for 16 PWMs).  Four waves per workgroup (a block staged per wave in a
+    // quarter of the span buffer), a cell each; the record says SUM_BEHIND and carries the sum.
+    const uint32_t xi = lin, xslot = xi >> 3;
+    constexpr uint32_t XW = (G::CELLS + 3u) / 4u;  // workgroups per PWM
+    const uint32_t pw = (xi & 7u) + 8u * (xslot / XW), cell = 4u * (xslot % XW) + wave;
+    if (pw >= n_pwm || wave >= 4u || cell >= G::CELLS || state[2 * pw + 1] == 0 || bad[pw]) return;
+    seqsum::lds_float* buf = (seqsum::lds_float*)span + wave * seqsum::BLOCK;
+    const float* w = wbuf + (size_t)pw * G::NP;
+    seqsum::Row mine;
+    if ((cell >> 2) == 0u) {
+      EmTerms0<W> src0{w, cell & 3u};
+      src0.bind_stage(lane);
+      src0.stage(0u, lane, buf);
+    } else {
+      EmTerms<W> src{w, cell >> 2, cell & 3u};
+      src.bind_stage(lane);
+      src.stage(0u, lane, buf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mine.read_staged(buf, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    seqsum::Stats st;
+    const float s0 = seqsum::fold_block(mine, lane, 0.0f, st);
+    if (lane == 0) {
+      seqsum::BlockRecord out;
+      out.e = seqsum::SUM_BEHIND;
+      out.d0 = s0;
+      out.d1 = 0.0f;
+      out.pad = 0u;
+      rec[((size_t)pw * G::CELLS + cell) * G::NBLK] = out;
+    }
+    return;
+  }
+  const uint32_t sl = lin - extra_wgs, slot = sl >> 3;
+  const uint32_t pw = (sl & 7u) + 8u * (slot / G::SPANS), sp = slot % G::SPANS;
+  if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
   constexpr uint32_t TASKS = (G::CELLS + SPAN_EVAL_WAVES - 1u) / SPAN_EVAL_WAVES;  // per wave
   seqsum::BlockRecord* cells = rec + (size_t)pw * G::CELLS * G::NBLK;
   // task (p, j) of the span -> its cell and block
@@ -1029,6 +1213,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
 #pragma unroll 1
   for (uint32_t task = wave, i = 0; task < G::CELLS; task += SPAN_EVAL_WAVES, ++i) {
     const uint32_t p = task >> 2, j = task & 3u;
+    if (block_of(task) == 0u) continue;  // (folded from zero by the workgroups behind the spans)
     seqsum::BlockRecord* r = cells + (size_t)cell_of(task) * G::NBLK + block_of(task);
     const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)binade[i][wave]);
     if (e == seqsum::NO_BINADE) {
@@ -1181,7 +1366,7 @@ namespace {
 // against 0.96 on one stream.  Starting the second lane when the first one's chains start, so that chains run beside
 // weights, was measured: 0.99 ms -- a chain's 32 KiB of LDS per wave halve the evaluation kernel's workgroups per CU.)
 // (PWMs are independent; every batch has its own tables, records and sums.)  `budget` = bytes of weight tables in flight.
-constexpr int EM_COUNTERS = 4;  // fetched, mispredicted, restaged, restaged_waits (seqsum::WalkCounts)
+constexpr int EM_COUNTERS = 4;  // fetched, mispredicted, restaged, restaged_waits (seqsum::WalkCounts); behind them: the background table's {min, max}
 template <int W>
 int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
                         const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change, size_t budget) {
@@ -1212,8 +1397,16 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   if (rc) return rc;
   rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes, lanes * blocks_b);
   if (rc) return rc;
-  if (!ctx->d_em_counters) PENGK_HIP(hipMalloc((void**)&ctx->d_em_counters, EM_COUNTERS * sizeof(unsigned long long)));
+  if (!ctx->d_em_counters) PENGK_HIP(hipMalloc((void**)&ctx->d_em_counters, (EM_COUNTERS + 1) * sizeof(unsigned long long)));
   PENGK_HIP(hipMemsetAsync(ctx->d_em_counters, 0, EM_COUNTERS * sizeof(unsigned long long), ctx->stream));  // per pengk_em call
+  // the range of the background table, for the weights kernel's choice of division (lean_ranges_ok)
+  uint32_t* bg_range = reinterpret_cast<uint32_t*>(ctx->d_em_counters + EM_COUNTERS);
+  {
+    const uint32_t init[2] = {ctx->em_lean_div ? 0xFFFFFFFFu : 0u, ctx->em_lean_div ? 0u : 0xFFFFFFFFu};  // (off: a range nothing accepts)
+    PENGK_HIP(hipMemcpyAsync(bg_range, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->em_lean_div)
+      hipLaunchKernelGGL(em_bg_range_kernel, dim3(32), dim3(1024), 0, ctx->stream, d_bg, (uint32_t)np, bg_range);  // (np = 4^W: a multiple of 4)
+  }
   hipStream_t streams[MAX_EM_LANES];
   streams[0] = ctx->stream;
   for (int l = 1; l < lanes; ++l) {
@@ -1245,15 +1438,17 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
       seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
       for (int it = 0; it < max_it; ++it) {
         hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
-                           d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums);
+                           d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums, (const uint32_t*)bg_range);
         if (!B::PREDICT_IN_EVAL)
           hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec,
                              (uint32_t)ctx->em_test_skew);
         const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
-        const uint64_t wgs = (uint64_t)groups * B::SPANS;
+        const uint64_t extra_wgs = (uint64_t)groups * ((B::CELLS + 3) / 4);  // block 0 of every cell, in front of ...
+        const uint64_t wgs = extra_wgs + (uint64_t)groups * B::SPANS;         // ... the spans
         const unsigned gx = 1024u;
         hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
-                           d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums, (uint32_t)ctx->em_test_skew);
+                           d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums, (uint32_t)ctx->em_test_skew,
+                           (uint32_t)extra_wgs);
         hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, d_state + 2 * first, (const float*)tables,
                            (const seqsum::BlockRecord*)rec, partials, bad, (uint32_t)nb, done, d_pwms + (size_t)first * W * 4,
                            d_change + first, threshold, max_it, ctx->d_em_counters);
@@ -1401,3 +1596,19 @@ int warm_em() {
 }
 
 }  // namespace pengk
+
+extern "C" int pengk_selftest_division(pengk_ctx* ctx, uint64_t seed, uint32_t pairs_per_thread, uint64_t* h_out) {
+  using namespace pengk;
+  if (!ctx || !h_out) return fail(PENGK_ERR_ARG, "pengk_selftest_division: NULL argument");
+  int rc = enter(ctx);
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, &ctx->d_misc, &ctx->misc_bytes, 3 * sizeof(unsigned long long));
+  if (rc) return rc;
+  PENGK_HIP(hipMemsetAsync(ctx->d_misc, 0, 3 * sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(em_div_check_kernel, dim3(4096), dim3(256), 0, ctx->stream, (unsigned long long)seed, pairs_per_thread,
+                     (unsigned long long*)ctx->d_misc);
+  PENGK_HIP(hipGetLastError());
+  PENGK_HIP(hipMemcpyAsync(h_out, ctx->d_misc, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  PENGK_HIP(hipStreamSynchronize(ctx->stream));
+  return PENGK_OK;
+}

@@ -49,6 +49,7 @@ struct pengk_ctx {
   int em_overlap = 2;           // K5 serial mode, em_serial_scan = 2: streams that batches of PWMs take turns on (1 .. MAX_EM_LANES)
   int em_serial_scan = 2;       // K5 serial mode: cells summed by 2 = the scan of seqsum.h with its blocks evaluated ahead of
                                 // the chain (W >= 10; else as 1), 1 = the scan, block after block, 0 = dependent additions
+  int em_lean_div = 1;          // K5 serial mode: the weights' divisions without range scaling where a PWM's operand ranges allow (em.hip, lean_div)
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms
   int scatter_blocks_per_cu = 0; // tuning hook: workgroups per CU of the partitioned scan (0 = default)

@@ -259,6 +259,8 @@ __device__ __forceinline__ float fold_block(const Row& mine, uint32_t lane, floa
 // power of two, the sum about to cross one) or whose test fails is evaluated by fold_block as before.  Exactness never
 // rests on the estimate: it only decides which blocks take the short way.
 constexpr uint32_t NO_BINADE = 0xFFFFFFFFu;
+// record of a chain's block 0 that was folded ahead of the chain (its start is known exactly: zero): d0 = the sum behind it
+constexpr uint32_t SUM_BEHIND = 0xFFFFFFFEu;
 // exponent field of the binade of s as bases_of sees it: zero, denormals and the lowest normal binade are one
 __device__ __forceinline__ uint32_t binade_of(float s) {
   const uint32_t e = bits(s) >> 23;
@@ -387,6 +389,11 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
       restaged = false;
     }
     uint32_t j = 0;
+    if (base == 0u && (uint32_t)__builtin_amdgcn_readfirstlane((int)r.x) == SUM_BEHIND) {
+      // block 0 was folded from zero by the kernel that evaluated the blocks (em_span_eval_kernel's extra workgroups)
+      s = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)r.y));
+      j = 1u;
+    }
 #pragma unroll 1
     while (j < 64u) {
       // the evaluated blocks from j on that share the binade of s: their increments compose like the rows of a block

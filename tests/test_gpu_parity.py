@@ -1123,3 +1123,51 @@ def test_motif_similarity_grid_within_margin_of_the_reference_arithmetic(ctx, bo
     pk._check(pk.lib().pengk_motif_similarity(ctx.h, n, pw.ctypes.data, cp.ctypes.data, lens.ctypes.data, sites.ctypes.data,
                                               int(both), bg.ctypes.data, n - 1, col.ctypes.data))
     assert np.array_equal(col, out[-(n - 1):])
+
+
+def test_lean_division_is_the_ieee_division_on_its_domain(ctx):
+    """The serial EM's weights kernel runs the IEEE division's own instruction sequence without its range scaling where a
+    PWM's operand ranges allow (csrc/em.hip, lean_div / lean_ranges_ok; the three divisions of
+    /root/reference/src/peng.cpp:124-125,186).  pengk_selftest_division draws ~3e9 random operand pairs -- exponents over the
+    whole range the guard admits, random and special mantissas, zero numerators -- and compares with the compiler's
+    division bit for bit: no pair may differ."""
+    import ctypes as C
+    total = bad = zeros = 0
+    for seed in (1, 2, 3):
+        out = (C.c_uint64 * 3)()
+        pk._check(pk.lib().pengk_selftest_division(ctx.h, seed, 1024, out))
+        total, bad, zeros = total + out[0], bad + out[1], zeros + out[2]
+    assert total > 10 ** 9 and zeros > 10 ** 6 and bad == 0, (total, bad, zeros)
+
+
+@pytest.mark.parametrize("W", [10, 12])
+def test_em_weights_with_and_without_the_lean_division(ctx, W):
+    """Same PWMs, same tables, option em_lean_div 1 / 0: the same bits -- on ordinary PWMs (which take the lean path), on
+    PWMs with entries of 1e-12 and 1e-30 (products far below the guard: the plain divisions), on a background table with a
+    zero entry (the whole call takes the plain divisions), and against the oracle for the first of them."""
+    NP = 4 ** W
+    rng = np.random.default_rng(31 + W)
+    c = rng.poisson(3.0, NP).astype(np.uint32)
+    c[rng.integers(0, NP, NP // 3)] = 0
+    bg = (rng.dirichlet(np.ones(64), size=NP // 64).reshape(-1)).astype(np.float32)
+    pwms = rng.dirichlet(np.ones(4) * 2, size=(6, W)).astype(np.float32)
+    pwms[3, :, 0] = np.float32(1e-12)
+    pwms[4, 2, 1] = np.float32(1e-30)
+    pwms[5] = np.float32(0.25)
+    counts = pk.DeviceArray.from_host(ctx, c)
+    got = {}
+    ctx.set_option("em_fast", 2)
+    try:
+        for tag, table in (("bg", bg), ("bg0", np.where(np.arange(NP) == 12345, np.float32(0), bg))):
+            bgd = pk.DeviceArray.from_host(ctx, table)
+            for lean in (1, 0):
+                ctx.set_option("em_lean_div", lean)
+                got[tag, lean] = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 2)
+    finally:
+        ctx.set_option("em_lean_div", 1)
+        ctx.set_option("em_fast", 1)
+    for tag in ("bg", "bg0"):
+        a, b = got[tag, 1], got[tag, 0]
+        assert a[0].tobytes() == b[0].tobytes() and a[1].tolist() == b[1].tolist() and a[2].tobytes() == b[2].tobytes(), tag
+    ref, it, ch = po.em(W, c.astype(np.uint64), bg, pwms[0], 1e4, 0.0, 2, mode=0, final_norm=False)
+    assert got["bg", 1][0][0].tobytes() == ref.astype(np.float32).tobytes()
