@@ -47,7 +47,7 @@ extern "C" {
 #define PENGK_ERR_UNSUPPORTED 4 /* operation not defined for this input (see function) */
 #define PENGK_ERR_NOMEM 5
 
-#define PENGK_MIN_W 4
+#define PENGK_MIN_W 2 /* the reference accepts every even pattern length (src/Global.cpp:103-106) */
 #define PENGK_MAX_W 14
 #define PENGK_FRONT_PAD_BASES 64
 #define PENGK_DEFAULT_ITEM_WINDOWS 256

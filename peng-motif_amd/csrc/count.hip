@@ -127,7 +127,9 @@ struct Suppress {
 #define PENGK_CX(n) "v_cmpx_ne_u32_e32 %2, %" #n "\n\t"
 #define PENGK_HEAD "s_mov_b64 %1, exec\n\t"
 #define PENGK_TAIL "v_mov_b32_e32 %0, %2\n\ts_mov_b64 exec, %1"
-    if constexpr (W == 4)
+    if constexpr (W == 2)
+      asm volatile(PENGK_HEAD PENGK_CX(3) PENGK_TAIL : "+v"(out), "=&s"(save) : "v"(can), PENGK_R(1) : "vcc");
+    else if constexpr (W == 4)
       asm volatile(PENGK_HEAD PENGK_CX(3) PENGK_CX(4) PENGK_CX(5) PENGK_TAIL
                    : "+v"(out), "=&s"(save) : "v"(can), PENGK_R(1), PENGK_R(2), PENGK_R(3) : "vcc");
     else if constexpr (W == 6)
@@ -150,7 +152,7 @@ struct Suppress {
                    : "v"(can), PENGK_R(1), PENGK_R(2), PENGK_R(3), PENGK_R(4), PENGK_R(5), PENGK_R(6), PENGK_R(7), PENGK_R(8),
                      PENGK_R(9), PENGK_R(10), PENGK_R(11) : "vcc");
     else {
-      static_assert(W == 14, "pattern lengths 4 .. 14");
+      static_assert(W == 14, "pattern lengths 2 .. 14");
       asm volatile(PENGK_HEAD PENGK_CX(3) PENGK_CX(4) PENGK_CX(5) PENGK_CX(6) PENGK_CX(7) PENGK_CX(8) PENGK_CX(9) PENGK_CX(10)
                    PENGK_CX(11) PENGK_CX(12) PENGK_CX(13) PENGK_CX(14) PENGK_CX(15) PENGK_TAIL
                    : "+v"(out), "=&s"(save)
@@ -1437,6 +1439,15 @@ int launch_count_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_lto
     if (d_bg) PENGK_HIP(hipMemsetAsync(d_bg, 0, 84 * sizeof(uint64_t), ctx->stream));
     return PENGK_OK;
   }
+  if constexpr (W < 4) {
+    // the fused K1b reads the 3-mers off the rolling id's top three digits: an id of two digits has none -- the
+    // stand-alone background count runs beside the scan
+    if (d_bg) {
+      const int rc_bg = launch_bg_count(ctx, d_bg);
+      if (rc_bg) return rc_bg;
+      d_bg = nullptr;
+    }
+  }
   int impl = ctx->count_impl;
   constexpr bool can_partition = (W == 8 || W == 10 || W == 12 || W == 14);
   if (impl == 0) impl = can_partition ? 2 : 1;
@@ -1486,6 +1497,7 @@ int launch_count(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot,
   PENGK_HIP(hipMemsetAsync(d_counts, 0, np * sizeof(uint32_t), ctx->stream));
   PENGK_HIP(hipMemsetAsync(d_ltot, 0, sizeof(uint64_t), ctx->stream));
   switch (W) {
+    case 2: return launch_count_w<2>(ctx, both, d_counts, d_ltot, d_bg);
     case 4: return launch_count_w<4>(ctx, both, d_counts, d_ltot, d_bg);
     case 6: return launch_count_w<6>(ctx, both, d_counts, d_ltot, d_bg);
     case 8: return launch_count_w<8>(ctx, both, d_counts, d_ltot, d_bg);

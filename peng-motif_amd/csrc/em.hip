@@ -1554,6 +1554,73 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   return PENGK_OK;
 }
 
+// W = 2 (16 patterns, 8 cells of 4 weights): the whole EM of a PWM in one wave -- the geometry above takes four digits of
+// the pattern from the thread index.  Lane x < 16 owns pattern x; per iteration: its weight with the reference's float
+// operations (src/peng.cpp:124-125, 180-197; mode 1: the throughput mode's one-reciprocal form), the cells' sums -- mode 2:
+// float32 in ascending x, the reference's order (:121-127); modes 0 and 1: fp64 -- and the reference's float32 epilogue
+// (row normalisation :129, change :132-137, swap :140-143) on lane 0, until the PWM has converged (:104).
+__global__ __launch_bounds__(64) void em_w2_kernel(float* __restrict__ pwms, int32_t* __restrict__ state, float* __restrict__ change_out,
+                                                   const uint32_t* __restrict__ counts, const float* __restrict__ bg, float saturation,
+                                                   float threshold, int max_it, int mode) {
+  const int pw = blockIdx.x, lane = threadIdx.x;
+  __shared__ float s_pwm[8], s_w[16];
+  __shared__ int s_active;
+  float* old = pwms + (size_t)pw * 8;
+  if (lane < 8) s_pwm[lane] = old[lane];
+  if (lane == 0) s_active = state[2 * pw + 1];
+  __syncthreads();
+  const float cs = lane < 16 ? (float)counts[lane] * saturation : 0.0f;
+  const float b = lane < 16 ? bg[lane] : 1.0f;
+  while (s_active) {
+    if (lane < 16) {
+      const float pr = (1.0f * s_pwm[lane & 3]) * s_pwm[4 + (lane >> 2)];
+      float w;
+      if (mode == 1) {
+        w = cs * pr * __builtin_amdgcn_rcpf(saturation * b + pr);
+      } else {
+        const float odds = pr / b;
+        w = cs / (1 + saturation / odds);
+      }
+      s_w[lane] = w;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      float nw[8];
+      for (int c = 0; c < 8; ++c) {
+        const int p = c >> 2, a = c & 3;
+        if (mode == 2) {
+          float acc = 0.0f;
+          for (int x = 0; x < 16; ++x)
+            if (((x >> (2 * p)) & 3) == a) acc += s_w[x];
+          nw[c] = acc;
+        } else {
+          double acc = 0.0;
+          for (int x = 0; x < 16; ++x)
+            if (((x >> (2 * p)) & 3) == a) acc += (double)s_w[x];
+          nw[c] = (float)acc;
+        }
+      }
+      float change = 0.0f;
+      for (int p = 0; p < 2; ++p) {
+        float sum = 0.0f;
+        for (int a = 0; a < 4; ++a) sum += nw[p * 4 + a];
+        for (int a = 0; a < 4; ++a) nw[p * 4 + a] /= sum;
+      }
+      for (int c = 0; c < 8; ++c) {
+        change += fabsf(nw[c] - s_pwm[c]);
+        s_pwm[c] = nw[c];
+      }
+      const int it = state[2 * pw] + 1;
+      state[2 * pw] = it;
+      s_active = !(change <= threshold || it >= max_it);
+      state[2 * pw + 1] = s_active;
+      change_out[pw] = change;
+    }
+    __syncthreads();
+  }
+  if (lane < 8) old[lane] = s_pwm[lane];
+}
+
 template <int W>
 int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
              const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
@@ -1578,6 +1645,13 @@ int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, flo
 int launch_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
               const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
   switch (W) {
+    case 2:
+      hipLaunchKernelGGL(em_init_kernel, dim3((unsigned)((n_pwm + 255) / 256)), dim3(256), 0, ctx->stream, (int)n_pwm, W, threshold, max_it,
+                         d_state, d_change);
+      hipLaunchKernelGGL(em_w2_kernel, dim3((unsigned)n_pwm), dim3(64), 0, ctx->stream, d_pwms, d_state, d_change, d_counts, d_bg,
+                         saturation, threshold, max_it, ctx->em_fast);
+      PENGK_HIP(hipGetLastError());
+      return PENGK_OK;
     case 4: return launch_w<4>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
     case 6: return launch_w<6>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
     case 8: return launch_w<8>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);

@@ -150,6 +150,7 @@ int launch_seed_candidates(pengk_ctx* ctx, int W, const float* d_z, const uint32
 int launch_stats(pengk_ctx* ctx, int W, int both, int k, int max_k, const float* d_V, const uint64_t* d_ltot,
                  const uint32_t* d_counts, float* d_bgprob, float* d_expected, float* d_logp, float* d_z) {
   switch (W) {
+    case 2: return launch_w<2>(ctx, both, k, max_k, d_V, d_ltot, d_counts, d_bgprob, d_expected, d_logp, d_z);
     case 4: return launch_w<4>(ctx, both, k, max_k, d_V, d_ltot, d_counts, d_bgprob, d_expected, d_logp, d_z);
     case 6: return launch_w<6>(ctx, both, k, max_k, d_V, d_ltot, d_counts, d_bgprob, d_expected, d_logp, d_z);
     case 8: return launch_w<8>(ctx, both, k, max_k, d_V, d_ltot, d_counts, d_bgprob, d_expected, d_logp, d_z);

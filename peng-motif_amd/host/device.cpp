@@ -287,6 +287,7 @@ bool sink_chunk(void* user, size_t, const SequenceChunk& c) {
 }  // namespace
 
 void begin_streaming_pack(int W) {
+  if (W < PENGK_MIN_W || W > PENGK_MAX_W) return;  // (Peng::process ends such a run with the reference's message)
   if (const char* e = std::getenv("PENGK_NO_STREAMING")) {  // the staged path: read, then pack, then upload (tests compare the two)
     if (std::atoi(e)) return;
   }

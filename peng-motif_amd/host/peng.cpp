@@ -300,6 +300,14 @@ void Peng::process(PengParameters& params, std::vector<IUPACPattern*>& best_iupa
     exit(1);
   }
   const size_t W = params.max_pattern_length;
+  if (W > (size_t)PENGK_MAX_W) {
+    // W = 16: the reference passes its own limit (11^16 < 2^64) and then asks for 4^16-entry tables -- 34 GB of counters,
+    // ~150 GB in all; its README advises W <= 12 (README.md:119).  This build's tables end at W = 14 (1 GiB each): the
+    // same two lines and exit code the reference gives a pattern length beyond ITS limit (src/peng.cpp:325-330).
+    std::cerr << "Warning: pattern length too long!" << std::endl;
+    std::cerr << "max pattern length: " << PENGK_MAX_W << std::endl;
+    exit(1);
+  }
   print_status("Processing kmers of length " + std::to_string(W), false);
   print_status("Finding overrepresented kmers (base patterns)", false);
   const int cur_k = std::min((int)W - 1, k), cur_max_k = std::min((int)W - 1, max_k);

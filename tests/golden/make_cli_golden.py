@@ -21,6 +21,10 @@ CASES = {
     "cli_mafk100_w8_bg1_enrich": ("MafK_100seqs.fasta", ["-w", "8", "--bg-model-order", "1", "--optimization_score", "ENRICHMENT", "-t", "6"]),
     "cli_mafk_w10_bg0_nofilter": ("MafK.fasta", ["-w", "10", "--bg-model-order", "0", "--no-neighbor-filtering", "--max-optimized-patterns", "12",
                                                   "--use-default-pwm", "--em-max-iterations", "3", "-a", "500", "--pseudo-counts", "20"]),
+    # W = 2 (round 4): with the default background order (min(W - 1, 2) = 1) a 2-mer is modelled exactly and nothing is
+    # ever a seed; order 0 gives seeds, a hill-climb, PWMs and an EM over 16 patterns
+    "cli_mafk_w2_bg0": ("MafK.fasta", ["-w", "2", "--bg-model-order", "0", "-t", "3", "--count-threshold", "1"]),
+    "cli_mafk100_w2": ("MafK_100seqs.fasta", ["-w", "2"]),
 }
 
 
@@ -29,7 +33,10 @@ def main():
         sys.exit("build the reference first: make -C oracle ref")
     out = os.path.join(HERE, "cli")
     os.makedirs(out, exist_ok=True)
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
     for name, (fasta, extra) in CASES.items():
+        if only and name not in only:
+            continue
         meme = os.path.join(out, name + ".meme")
         js = os.path.join(out, name + ".json")
         cmd = [REF, os.path.join(HERE, fasta)] + extra + ["-o", meme, "-j", js]

@@ -36,6 +36,10 @@ CASES = [
     ("torture_w8_plus", "torture.fa", 8, "PLUS"),
     ("mafk_w10_both", "MafK.fasta", 10, "BOTH"),            # BASELINE config 2
     ("mafk_w10_plus", "MafK.fasta", 10, "PLUS"),
+    # W = 2 (round 4): the shortest pattern length the reference accepts (any even W, src/Global.cpp:103-106); its
+    # background order is min(W - 1, 2) = 1, which models 2-mers exactly -- z ~ 0, no seeds, the tables are the test
+    ("torture_w2_both", "torture.fa", 2, "BOTH"),
+    ("mafk100_w2_plus", "MafK_100seqs.fasta", 2, "PLUS"),
 ]
 
 
@@ -187,7 +191,10 @@ def main():
     if not os.path.exists(REF_DUMP):
         sys.exit("build the reference first: make -C oracle ref")
     ok = True
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
     for c in CASES:
+        if only and c[0] not in only:
+            continue
         ok &= run_case(*c)
     sys.exit(0 if ok else 1)
 

@@ -10,7 +10,7 @@ and writes to tests/golden/shard_prefix_checksums.json
 
   * one row per shard: sha256 of its (mirrored) uint32 count table, ltot, the 84 background counters -- all the
     reference's own numbers;
-  * one row per prefix k = 2, 4, 8: sha256 of the SUM of the first k tables, sum of ltot, sum of the counters (the
+  * one row per prefix k = 1, 2, 4, 8: sha256 of the SUM of the first k tables, sum of ltot, sum of the counters (the
     reference's numbers, added), and -- derived from those sums by the oracle's sweep, which is pinned against the
     reference elsewhere and labelled "oracle on reference sums" here -- sha256 of V and of z.
 
@@ -41,7 +41,7 @@ JOBS = [  # name, seed, n per shard, L, W, strand, shards
     # bench.py's weak scaling of BASELINE configs[2]: rank r holds sequences [r * 10M, (r + 1) * 10M)
     ("configs2_weak", 1, 10_000_000, 200, 10, "BOTH", 8),
 ]
-PREFIXES = (2, 4, 8)
+PREFIXES = (1, 2, 4, 8)  # (k = 1: what one rank must produce -- shard 0 -- with the oracle's V and z beside it)
 
 
 def sha(a):

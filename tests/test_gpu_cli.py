@@ -21,7 +21,7 @@ SELFTEST = os.path.join(HOST, "host_selftest")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 CASES = ["cli_mafk100_w8", "cli_mafk100_w6_plus_noem", "cli_mafk100_w8_logpval_nomerge", "cli_mafk_w10", "cli_mafk_w10_plus",
-         "cli_torture_w6", "cli_mafk100_w8_bg1_enrich", "cli_mafk_w10_bg0_nofilter"]
+         "cli_torture_w6", "cli_mafk100_w8_bg1_enrich", "cli_mafk_w10_bg0_nofilter", "cli_mafk_w2_bg0", "cli_mafk100_w2"]
 
 
 def parse_meme(path):
@@ -236,3 +236,16 @@ def test_merging_through_the_device_similarity_grid_prints_what_the_exact_path_p
         outs.append((r.stdout, meme.read_bytes(), js.read_bytes()))
     assert outs[0][0].count(b"\nmerge: ") >= 20 and outs[0][0].count(b"\nem: ") >= 150
     assert outs[0] == outs[1]
+
+
+def test_pattern_lengths_beyond_the_tables_end_like_the_references_too_long(tmp_path):
+    """W = 16 passes the reference's own limit (11^16 < 2^64, /root/reference/src/peng.cpp:325-330) and then needs 4^16-entry
+    tables (~150 GB there; its README advises W <= 12).  This build's tables end at W = 14: the run ends with the two
+    lines and the exit code the reference gives a pattern length beyond its limit -- after reading the input, like the
+    reference -- and W = 18, beyond both limits, prints the reference's own numbers."""
+    cli = os.path.join(HOST, "peng_motif")
+    fa = os.path.join(GOLD, "MafK_100seqs.fasta")
+    r = subprocess.run([cli, fa, "-w", "16"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 1 and b"Warning: pattern length too long!" in r.stderr and b"max pattern length: 14" in r.stderr
+    r = subprocess.run([cli, fa, "-w", "18"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 1 and b"Warning: pattern length too long!" in r.stderr and b"max pattern length: 31" in r.stderr

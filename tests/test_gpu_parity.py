@@ -17,7 +17,7 @@ from oracle import oracle as po
 pytestmark = pytest.mark.gpu
 
 CASES = ["mafk100_w8_both", "mafk100_w8_plus", "mafk100_w6_both", "torture_w6_both", "torture_w6_plus",
-         "torture_w4_both", "torture_w8_plus", "mafk_w10_both", "mafk_w10_plus"]
+         "torture_w4_both", "torture_w8_plus", "mafk_w10_both", "mafk_w10_plus", "torture_w2_both", "mafk100_w2_plus"]
 
 
 @pytest.fixture(scope="module")
@@ -1171,3 +1171,40 @@ def test_em_weights_with_and_without_the_lean_division(ctx, W):
         assert a[0].tobytes() == b[0].tobytes() and a[1].tolist() == b[1].tolist() and a[2].tobytes() == b[2].tobytes(), tag
     ref, it, ch = po.em(W, c.astype(np.uint64), bg, pwms[0], 1e4, 0.0, 2, mode=0, final_norm=False)
     assert got["bg", 1][0][0].tobytes() == ref.astype(np.float32).tobytes()
+
+
+@pytest.mark.parametrize("name", ["torture_w2_both", "mafk100_w2_plus"])
+def test_w2_iupac_and_em_against_the_oracle(ctx, golden_dir, name):
+    """W = 2 (the shortest pattern length the reference accepts, /root/reference/src/Global.cpp:103-106): no golden run
+    has a seed at W = 2 -- the order-1 background models 2-mers exactly -- so the IUPAC aggregation (all 121 two-letter
+    IUPAC patterns) and the EM (the one-wave kernel em_w2_kernel, all three modes) are checked against the oracle on the
+    reference-pinned tables of the golden case: aggregates and serial-mode PWMs bit for bit, the fp64 modes within 1e-6."""
+    r = cpu_pipeline(golden_dir, name)
+    W, K, both = r["W"], r["K"], r["both"]
+    assert W == 2
+    d = gpu_tables(ctx, r)
+    bgp_k = pk.DeviceArray.from_host(ctx, d["bgprob"].to_host()[K])
+    ids = np.arange(121, dtype=np.uint64)
+    out = ctx.iupac_aggregate(W, both, ids, d["counts"], bgp_k, d["expected"])
+    for i in ids.tolist():
+        st = po.iupac_aggregate(i, W, both, r["counts"], r["bgp"][K], r["expected"])
+        assert out["sites"][i] == st.sites == po.iupac_count(i, W, both, r["counts"])
+        got = np.array([out["bg_p"][i], out["expected"][i], out["zscore"][i]], np.float32).view(np.uint32)
+        want = np.array([st.bg_p, st.expected, st.zscore], np.float32).view(np.uint32)
+        assert np.array_equal(got, want), po.iupac_str(i, W)
+    rng = np.random.default_rng(2)
+    pwms = rng.dirichlet(np.ones(4), size=(7, W)).astype(np.float32)
+    pwms[6] = np.float32(0.25)
+    for mode, omode, tol in ((2, 0, 0.0), (0, 1, 1e-6), (1, 1, 1e-5)):
+        ctx.set_option("em_fast", mode)
+        try:
+            got, iters, change = ctx.em(W, pwms, d["counts"], bgp_k, 1e4, 0.01, 10)
+        finally:
+            ctx.set_option("em_fast", 1)
+        for i in range(len(pwms)):
+            ref, it, ch = po.em(W, r["counts"], r["bgp"][K], pwms[i], 1e4, 0.01, 10, mode=omode, final_norm=False)
+            if tol == 0.0:
+                assert iters[i] == it and got[i].tobytes() == ref.astype(np.float32).tobytes(), (mode, i)
+                assert np.float32(change[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
+            else:
+                assert abs(int(iters[i]) - it) <= (0 if mode == 0 else 1) and np.abs(got[i].astype(np.float64) - ref).max() <= tol * 10, (mode, i)

@@ -44,7 +44,7 @@ def ctx():
 def test_shards_counted_one_after_the_other_add_up_to_the_reference_sums(ctx, job):
     shards = sorted(rows_of(job, "shard"), key=lambda r: r["shard"])
     prefixes = {r["k"]: r for r in rows_of(job, "prefix")}
-    assert len(shards) == 8 and sorted(prefixes) == [2, 4, 8]
+    assert len(shards) == 8 and sorted(prefixes) == [1, 2, 4, 8]
     W, L, n, both = shards[0]["W"], shards[0]["L"], shards[0]["n_per_shard"], shards[0]["strand"] == "BOTH"
     NP = 4 ** W
     tot = np.zeros(NP, np.uint64)

@@ -10,7 +10,7 @@ import pytest
 from oracle import oracle as po
 
 CASES = ["mafk100_w8_both", "mafk100_w8_plus", "mafk100_w6_both", "torture_w6_both", "torture_w6_plus",
-         "torture_w4_both", "torture_w8_plus", "mafk_w10_both", "mafk_w10_plus"]
+         "torture_w4_both", "torture_w8_plus", "mafk_w10_both", "mafk_w10_plus", "torture_w2_both", "mafk100_w2_plus"]
 
 
 def sha(a):
