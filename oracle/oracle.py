@@ -34,6 +34,7 @@ def lib():
         L.po_count.argtypes = [u8p, i64p, C.c_int64, C.c_int, C.c_int, u64p, u64p]
         L.po_bg_counts.argtypes = [u8p, i64p, C.c_int64, C.c_int, i64p]
         L.po_bg_V.argtypes = [i64p, C.c_int, f32p, f32p]
+        L.po_bg_V64.argtypes = [i64p, C.c_int, f32p, f32p]
         L.po_bgprob.argtypes = [C.c_int, C.c_int, f32p, C.c_int, f32p]
         L.po_stats.argtypes = [C.c_int, u64p, f32p, C.c_uint64, f32p, f32p, f32p]
         L.po_select.restype = C.c_int64
@@ -98,11 +99,13 @@ def bg_counts(codes, offs, K=2):
     return out
 
 
-def bg_V(n, K=2, alpha=(1.0, 1.0, 1.0)):
+def bg_V(n, K=2, alpha=(1.0, 1.0, 1.0), wide=False):
+    """wide=False: the reference's `int` counters (wrap beyond 2^31 bases); wide=True: 64-bit counters, the intended
+    semantics the product computes -- identical below 2^31 bases."""
     n = np.ascontiguousarray(n, np.int64)
     a = np.asarray(alpha, np.float32)
     V = np.zeros(len(n), np.float32)
-    lib().po_bg_V(_p(n, C.c_int64), K, _p(a, C.c_float), _p(V, C.c_float))
+    (lib().po_bg_V64 if wide else lib().po_bg_V)(_p(n, C.c_int64), K, _p(a, C.c_float), _p(V, C.c_float))
     return V
 
 

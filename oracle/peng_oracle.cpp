@@ -224,7 +224,8 @@ PO_API void po_bg_counts(const uint8_t* codes, const int64_t* offs, int64_t nseq
 
 // calculateV, src/shared/BackgroundModel.cpp:490-530 (interpolate = true).  The reference keeps
 // `int` counters (:54-56); counts are converted int -> float exactly as static_cast<float> does.
-PO_API void po_bg_V(const int64_t* n, int K, const float* alpha, float* V /* same layout as n */) {
+template <class I>
+static void bg_V_impl(const int64_t* n, int K, const float* alpha, float* V) {
   const int64_t* nk[3];
   float* vk[3];
   {
@@ -237,17 +238,17 @@ PO_API void po_bg_V(const int64_t* n, int K, const float* alpha, float* V /* sam
       q += 1ll << (2 * (k + 1));
     }
   }
-  int base_counts = 0;
-  for (int y = 0; y < 4; ++y) base_counts += (int)nk[0][y];
+  I base_counts = 0;
+  for (int y = 0; y < 4; ++y) base_counts += (I)nk[0][y];
   for (int y = 0; y < 4; ++y)
-    vk[0][y] = ((float)(int)nk[0][y] + alpha[0] * 0.25f) / ((float)base_counts + alpha[0]);
+    vk[0][y] = ((float)(I)nk[0][y] + alpha[0] * 0.25f) / ((float)base_counts + alpha[0]);
   for (int k = 1; k <= K; ++k) {
     const int ny = 1 << (2 * (k + 1));
     const int yk = 1 << (2 * k);
     for (int y = 0; y < ny; ++y) {
       const int y2 = y % yk;  // drop the oldest base
       const int yp = y / 4;   // drop the newest base
-      vk[k][y] = ((float)(int)nk[k][y] + alpha[k] * vk[k - 1][y2]) / ((float)(int)nk[k - 1][yp] + alpha[k]);
+      vk[k][y] = ((float)(I)nk[k][y] + alpha[k] * vk[k - 1][y2]) / ((float)(I)nk[k - 1][yp] + alpha[k]);
     }
     for (int g = 0; g < ny; g += 4) {  // :519-528 normalise each context group by its running sum
       float factor = 0.0f;
@@ -256,6 +257,13 @@ PO_API void po_bg_V(const int64_t* n, int K, const float* alpha, float* V /* sam
     }
   }
 }
+
+// the reference's arithmetic: `int` counters and an `int` base count (src/shared/BackgroundModel.cpp:492-495) -- which WRAP
+// beyond 2^31 bases, i.e. for every shard of BASELINE configs[3] (2.5e9 bases) -- ...
+PO_API void po_bg_V(const int64_t* n, int K, const float* alpha, float* V /* same layout as n */) { bg_V_impl<int>(n, K, alpha, V); }
+// ... and the intended semantics the product computes (64-bit counters; identical below 2^31 bases): what the
+// reference-derived rows of sets beyond that size are built with (tests/golden/make_shard_golden.py), labelled so there
+PO_API void po_bg_V64(const int64_t* n, int K, const float* alpha, float* V) { bg_V_impl<int64_t>(n, K, alpha, V); }
 
 // ---------------------------------------------------------------------------------------------
 // Per-pattern background probability of order k (src/base_pattern.cpp:285-325), float32 product

@@ -105,13 +105,20 @@ def main():
             k = s + 1
             if k in PREFIXES:
                 assert int(tot.max()) < 2 ** 32
-                V = po.bg_V(bg, 2)
+                # 64-bit counters: the reference's `int` counters and base count wrap beyond 2^31 bases
+                # (src/shared/BackgroundModel.cpp:492-495) -- every row here but the 2.0e9-base one is beyond that; below
+                # it the two agree bit for bit (asserted), and that row's V / z equal the reference's own
+                # (tests/golden/synth_checksums.json)
+                V = po.bg_V(bg, 2, wide=True)
+                if int(bg[:4].sum()) < 2 ** 31:
+                    assert V.tobytes() == po.bg_V(bg, 2).tobytes()
                 bgp = po.bgprob(W, 2, V, strand == "BOTH")
                 e, lp, z = po.stats(W, tot, bgp, lt)
                 out.append(dict(base, kind="prefix", k=k, n_seq=k * n, ltot=lt, sha_counts_u32=sha(tot.astype(np.uint32)),
                                 bgcounts=bg.tolist(), source="compiled reference, per-shard tables added",
                                 sha_V=sha(V), sha_bgp2=sha(bgp), sha_expected=sha(e), sha_z=sha(z),
-                                derived="V, bgp2, expected, z: the oracle's sweep on the reference's summed tables"))
+                                derived="V, bgp2, expected, z: the oracle's sweep on the reference's summed tables, background counters in "
+                                        "64 bits (the reference's int counters wrap beyond 2^31 bases; identical below)"))
                 print("%s prefix %d: ltot %d" % (name, k, lt), flush=True)
             json.dump(out, open(out_path, "w"), indent=1)
     json.dump(out, open(out_path, "w"), indent=1)
