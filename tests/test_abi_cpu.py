@@ -113,12 +113,14 @@ def test_packer_items_and_flags(golden_dir):
 def test_packer_argument_errors():
     codes = np.array([1, 2, 3, 4] * 5, np.uint8)
     offs = np.array([0, 20], np.int64)
-    for W in (3, 5, 16, 2):
+    for W in (3, 5, 16, 0):  # (W = 2 is a pattern length since round 4: the reference accepts every even W)
         with pytest.raises(pk.PengkError) as e:
             pk.Packed(codes, offs, W)
         assert e.value.code == pk.ERR_ARG
     with pytest.raises(pk.PengkError):
         pk.Packed(codes, offs, 8, 8)  # item_windows below the minimum
+    p2 = pk.Packed(codes, offs, 2)
+    assert p2.n_windows == 19 and p2.W == 2
     p = pk.Packed(codes[:0], np.array([0], np.int64), 8)  # empty input is fine
     assert p.n_windows == 0 and len(p.items) == 0
 
