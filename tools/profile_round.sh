@@ -8,7 +8,7 @@ set -e
 export TMPDIR=/tmp
 R=$PWD; T=$1; shift; CFG="$@"; OUT=$R/gpurun_out/$T
 mkdir -p $OUT
-BARGS="--no-cpu-baseline --no-e2e --k4-patterns 0 $CFG"
+BARGS="--no-cpu-baseline --no-e2e --k4-patterns 0 --config3-steps 0 $CFG"   # (the configs[3] leg has its own tag: r0N_w12)
 STRESS=""; [ -n "$CFG" ] && STRESS="--em-stress-pwms 0"
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 3 --warmup 1 $BARGS $STRESS > $OUT/stats.log 2>&1
@@ -22,4 +22,4 @@ done
 cd $R
 if [ -z "$CFG" ]; then python3 bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 else python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e $CFG > $OUT/bench.json 2> $OUT/bench.err; fi
-python3 tools/profile_summary.py $OUT
+python3 tools/profile_summary.py $OUT $PENGK_COMMIT   # (no .git on the GPU box: the caller passes the commit)
