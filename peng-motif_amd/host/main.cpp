@@ -39,6 +39,14 @@ struct PhaseClock {
           std::cerr << "[timing] resident memory at the end: " << std::atof(line + 6) / 1024.0 << " MiB" << std::endl;
       std::fclose(f);
     }
+    // how much of it sits on transparent huge pages: what the kernel has to take back page by page at exit is the rest
+    if (FILE* f = std::fopen("/proc/self/smaps_rollup", "r")) {
+      char line[256];
+      while (std::fgets(line, sizeof line, f))
+        if (std::strncmp(line, "AnonHugePages:", 14) == 0)
+          std::cerr << "[timing] of it on transparent huge pages: " << std::atof(line + 14) / 1024.0 << " MiB" << std::endl;
+      std::fclose(f);
+    }
   }
 };
 }  // namespace
