@@ -15,7 +15,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "peng_motif_ref")
 
 def make_case(seed, tmp):
     rng = np.random.default_rng(9000 + seed)
-    W = int(rng.choice([4, 6, 8, 8, 10, 10, 12]))
+    W = int(rng.choice([int(x) for x in os.environ["PENGK_DIFF_WS"].split(",")] if os.environ.get("PENGK_DIFF_WS") else [4, 6, 8, 8, 10, 10, 12]))
     n, L = int(rng.integers(100, 1200)) * int(os.environ.get("SCALE", "1")), int(rng.integers(max(W + 2, 30), 260))
     motifs = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(6, 14)))) for _ in range(int(rng.integers(1, 5)))]
     p_n = float(rng.choice([0.0, 0.02, 0.2]))
