@@ -1402,8 +1402,10 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   // the range of the background table, for the weights kernel's choice of division (lean_ranges_ok)
   uint32_t* bg_range = reinterpret_cast<uint32_t*>(ctx->d_em_counters + EM_COUNTERS);
   {
-    const uint32_t init[2] = {ctx->em_lean_div ? 0xFFFFFFFFu : 0u, ctx->em_lean_div ? 0u : 0xFFFFFFFFu};  // (off: a range nothing accepts)
-    PENGK_HIP(hipMemcpyAsync(bg_range, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    // {min, max} start as {all ones, 0}; with the option off they stay {0, all ones}: a range nothing accepts
+    // (two 32-bit fills, no host buffer that would have to outlive an asynchronous copy)
+    PENGK_HIP(hipMemsetD32Async((hipDeviceptr_t)bg_range, ctx->em_lean_div ? (int)0xFFFFFFFFu : 0, 1, ctx->stream));
+    PENGK_HIP(hipMemsetD32Async((hipDeviceptr_t)(bg_range + 1), ctx->em_lean_div ? 0 : (int)0xFFFFFFFFu, 1, ctx->stream));
     if (ctx->em_lean_div)
       hipLaunchKernelGGL(em_bg_range_kernel, dim3(32), dim3(1024), 0, ctx->stream, d_bg, (uint32_t)np, bg_range);  // (np = 4^W: a multiple of 4)
   }
