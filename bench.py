@@ -67,6 +67,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end peng_motif CLI run on the config's FASTA")
     ap.add_argument("--e2e-runs", type=int, default=5, help="runs of the peng_motif CLI on the config's FASTA (the median is reported)")
+    ap.add_argument("--e2e-pause", type=float, default=1.0, help="seconds between those runs (a finished run's teardown in the driver slows the next one's start)")
     ap.add_argument("--count-impl", type=int, default=0, help="0 auto, 1 direct atomics, 2 partitioned")
     ap.add_argument("--cpu-sample-seqs", type=int, default=6_000_000)
     ap.add_argument("--checks", action="store_true", help="(kept for old command lines: the checksums are always on the line now)")
@@ -765,6 +766,11 @@ def e2e_cli(args, W, both, L, nseq):
                os.path.join(tmp, "o.json")]
         runs = []
         for rep in range(args.e2e_runs):  # (the first run also warms the page cache and the GPU code-object cache)
+            # A process that has used the GPU is still being torn down in the driver for a while after it has gone, and a
+            # process that starts in that window pays for it: back to back the runs took 0.19-0.48 s on one box (runtime
+            # start up to 220 ms, exits of 0.15-0.18 s), one second apart 0.185-0.23 s, every one of them
+            # (tools/e2e_gap.sh, profiles/r04_e2e_experiments.log).  A user starts the program once: the runs are spaced.
+            time.sleep(args.e2e_pause)
             t0 = time.perf_counter()
             p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                                  env=dict(os.environ, PENGK_TIMING="1", PENGK_TIMING_CREATE="1"))
@@ -794,7 +800,7 @@ def e2e_cli(args, W, both, L, nseq):
         mid = min(runs, key=lambda r_: abs(r_["wall_s"] - median))
         n_motifs = sum(1 for l in open(os.path.join(tmp, "o.meme")) if l.startswith("MOTIF"))
         is_c2 = (nseq, L, W, both) == (10_000_000, 200, 10, True)
-        res = {"wall_s": round(median, 3), "wall_s_is": "median of %d runs" % len(runs), "walls_s": [r_["wall_s"] for r_ in runs],
+        res = {"wall_s": round(median, 3), "wall_s_is": "median of %d runs, %.1f s apart" % (len(runs), args.e2e_pause), "walls_s": [r_["wall_s"] for r_ in runs],
                "best_wall_s": walls[0], "phases_s": mid["phases_s"], "runtime_start_ms": mid["runtime_start_ms"],
                "exit_s": mid["exit_s"], "before_main_s": mid["before_main_s"], "runs": runs,
                "motifs": n_motifs, "fasta_bytes": os.path.getsize(fa),
