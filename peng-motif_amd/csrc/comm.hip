@@ -39,7 +39,6 @@
 
 #include <chrono>
 #include <condition_variable>
-#include <fcntl.h>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -585,7 +584,7 @@ int pengk_comm_init_env(pengk_ctx* ctx) {
     return fail(PENGK_ERR_ARG, "PENGK_COMM_TRANSPORT=%s (rccl or tcp)", transport);
   // Nobody enters ncclCommInitRank before EVERY rank has said, over the host channel (which has deadlines), that it
   // can: librccl loaded on all of them, the id created on rank 0.  PENGK_COMM_TEST_FAIL_LOAD=<rank> is the test hook
-  // that makes one rank fail here (tests/test_host_channel_cpu.py).
+  // that makes one rank fail here (tests/test_gpu_multirank.py).
   int32_t loaded = load_rccl_or_test_failure(rank);
   rc = chan_agree(loaded, "could not load librccl");
   if (rc) return rc;
