@@ -296,6 +296,22 @@ def config3_leg(rt, args):
            "count_ms": round(leg.acc["count"] / n, 4), "exchange_ms": round(leg.acc["exchange"] / n, 4),
            "exchange_bytes": 4 * 4 ** W + 8 * 85, "sweep_ms": round(leg.acc["sweep"] / n, 4), "em_ms": round(leg.acc["em"] / n, 4),
            "ltot_global": int(leg.scal[84].item()), "checks": leg.checks, "checks_ok": leg.checks_ok}
+    # the leg's own K1 roofline (same definition as the line's: SURVEY.md 8d algorithmic bytes / the HIP-event time of the count)
+    count_ms = leg.acc["count"] / n
+    alg = (nseq * L + 3) // 4 + 8 * int(leg.ni.value) + 4 * 4 ** W
+    ach = alg / (count_ms * 1e-3) / 1e9 if count_ms > 0 else 0.0
+    out["roofline"] = {"kernel": "pengk_count_bg = count_scatter12_kernel<both> + count_rescatter12_kernel + count_hist_kernel + count_gather12_kernel (K1 two-level, K1b fused)",
+                       "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+                       "traffic": None, "algorithmic_bytes_per_launch": alg}
+    prof = os.path.join(ROOT, "profiles", "traffic_by_config.json")
+    try:
+        pj = json.load(open(prof)).get(config_key(nseq, L, W, both))
+        if pj:
+            out["roofline"]["traffic"] = pj.get("count_kernel_hbm_bytes_per_launch")
+            out["roofline"]["traffic_source"] = "profiles/traffic_by_config.json[%s]: rocprofv3 --pmc passes at commit %s, not this run" % (
+                config_key(nseq, L, W, both), pj.get("commit", "?"))
+    except Exception:  # noqa: BLE001 -- no profile of this size: no traffic figure
+        pass
     return out
 
 

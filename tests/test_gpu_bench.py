@@ -246,4 +246,6 @@ def test_the_bench_line_verifies_itself_against_the_reference_at_full_size(gpus,
     c3 = d["components"]["config3"]
     assert c3["checks_ok"]["ok"] is True and "configs3, k=%d" % gpus in c3["checks_ok"]["against"], c3["checks_ok"]
     assert c3["ltot_global"] == gpus * 12_500_000 * 189 and c3["exchange_bytes"] == 67109544
+    r3 = c3["roofline"]  # the leg's own K1 roofline, traffic from the committed W = 12 profile
+    assert r3["bound"] == "hbm" and abs(r3["frac"] - r3["achieved"] / r3["peak"]) < 1e-6 and r3["traffic"] > r3["algorithmic_bytes_per_launch"]
     assert d["components"]["config4"]["split_equals_1rank_bit_for_bit"] is True
