@@ -385,6 +385,9 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        sys.exit("bench.py: --gpus %d but the launcher started %s rank(s); start it as `python bench.py --gpus N` or with "
+                 "--nproc-per-node equal to --gpus" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
     # ---- end to end, first: the peng_motif CLI on the config's FASTA, before this process touches the GPU -------------
     e2e_state = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("PENGK_BENCH_FORCE_COMM") and not args.no_e2e:
