@@ -85,7 +85,8 @@ int pengk_malloc(pengk_ctx* ctx, size_t bytes, void** d_out);
 int pengk_free(pengk_ctx* ctx, void* d_ptr);
 int pengk_memcpy_h2d(pengk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* synchronous */
 int pengk_memcpy_d2h(pengk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous */
-/* Pays the process's first-use costs ahead of time (first device-to-host copy: 10-17 ms whatever its size; the code
+/* (No counterpart in the reference, whose process has no device runtime to start.)
+ * Pays the process's first-use costs ahead of time (first device-to-host copy: 10-17 ms whatever its size; the code
  * objects of the sweep / IUPAC / EM / similarity kernels).  Optional; call once after pengk_create, from any thread,
  * beside other work. */
 int pengk_warmup(pengk_ctx* ctx);
