@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--count-impl", type=int, default=0, help="0 auto, 1 direct atomics, 2 partitioned")
     ap.add_argument("--cpu-sample-seqs", type=int, default=6_000_000)
     ap.add_argument("--checks", action="store_true", help="(kept for old command lines: the checksums are always on the line now)")
+    ap.add_argument("--pipelined", type=int, default=1, help="1: also time the passes as a two-stream pipeline (components.pipelined); 0: skip")
     ap.add_argument("--config3-steps", type=int, default=3,
                     help="timed steps of the BASELINE configs[3] leg (W=12, one 12.5M x 200 bp shard per rank, 64 MiB exchange); 0 = skip")
     ap.add_argument("--config3-nseq", type=int, default=12_500_000, help="sequences per rank in the configs[3] leg")
@@ -278,6 +279,75 @@ def run_leg(rt, W, both, L, nseq, P_total, em_iters, steps, warmup, em_fast):
                              alpha=alpha, acc=acc, dt=dt, exchange=exchange, step=step, seed_pwms=seed_pwms, checks=checks,
                              checks_ok=checks_ok, barrier=barrier))
     return leg
+
+
+def pipelined_leg(rt, args, leg, W, both, steps, warmup):
+    """The same K passes as the main leg, as a THROUGHPUT pipeline over independent batches (not the line's `value`, which
+    stays one pass after the other): the EM of batch i -- 0.85 ms of mostly latency, a few hundred waves -- runs on a second
+    stream and context while the first one already counts batch i + 1 (2.9 ms of issue-bound scan on every CU).  Two sets
+    of tables; events order count(i) -> EM(i) and EM(i) -> count(i + 2) on the set they share.  Nothing is skipped: every
+    pass runs count + exchange + mirror + V + sweep + EM in the CLI's bit-exact mode, and the last two passes' tables and
+    PWMs are compared with the main leg's (same input => same bits)."""
+    torch, pk, lib, ctx, dist, dev = rt.torch, rt.pk, rt.lib, rt.ctx, rt.dist, rt.dev
+    NP, K = 4 ** W, 2
+    s0 = torch.cuda.current_stream()
+    s1 = torch.cuda.Stream(device=dev)
+    ctx2 = pk.Context(dev.index)
+    pk._check(lib.pengk_set_stream(ctx2.h, s1.cuda_stream))
+    ctx2.set_option("em_fast", args.em_fast)
+    ctx2.set_option("em_serial_scan", args.em_serial_scan)
+    sets = []
+    for _ in range(2):
+        sets.append(dict(counts=torch.empty(NP, dtype=torch.int32, device=dev), scal=torch.zeros(85, dtype=torch.int64, device=dev),
+                         V=torch.empty(84, dtype=torch.float32, device=dev), bgprob=torch.empty((K + 1, NP), dtype=torch.float32, device=dev),
+                         expected=torch.empty(NP, dtype=torch.float32, device=dev), logp=torch.empty(NP, dtype=torch.float32, device=dev),
+                         z=torch.empty(NP, dtype=torch.float32, device=dev), pwms=torch.empty_like(leg.pw_init),
+                         state=torch.zeros_like(leg.em_state), change=torch.zeros_like(leg.em_change),
+                         ready=torch.cuda.Event(), em_done=torch.cuda.Event()))
+    alpha = leg.alpha
+
+    def one(i):
+        t = sets[i & 1]
+        if i >= 2:
+            s0.wait_event(t["em_done"])  # the EM of batch i - 2 has read this set's tables
+        pk._check(lib.pengk_count_bg(ctx.h, int(both), t["counts"].data_ptr(), t["scal"][84:].data_ptr(), t["scal"].data_ptr()))
+        if rt.rccl_ranks:
+            pk._check(lib.pengk_allreduce_tables(ctx.h, W, t["counts"].data_ptr(), t["scal"][84:].data_ptr(), t["scal"].data_ptr()))
+        else:
+            rt.sharding.allreduce_tables(t["counts"], t["scal"], dist)
+        if both:
+            pk._check(lib.pengk_mirror_counts(ctx.h, W, t["counts"].data_ptr()))
+        pk._check(lib.pengk_bg_model(ctx.h, t["scal"].data_ptr(), K, alpha.ctypes.data, t["V"].data_ptr()))
+        pk._check(lib.pengk_pattern_stats(ctx.h, W, int(both), K, K, t["V"].data_ptr(), t["scal"][84:].data_ptr(), t["counts"].data_ptr(),
+                                          t["bgprob"].data_ptr(), t["expected"].data_ptr(), t["logp"].data_ptr(), t["z"].data_ptr()))
+        t["ready"].record(s0)
+        with torch.cuda.stream(s1):
+            s1.wait_event(t["ready"])
+            t["pwms"].copy_(leg.pw_init)
+            if leg.n_my:
+                pk._check(lib.pengk_em_device(ctx2.h, W, leg.n_my, t["pwms"].data_ptr(), 1e4, 0.0, args.em_iters, t["counts"].data_ptr(),
+                                              t["bgprob"][K].data_ptr(), t["state"].data_ptr(), t["change"].data_ptr()))
+            t["em_done"].record(s1)
+
+    for i in range(warmup):
+        one(i)
+    leg.barrier()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        one(i)
+    leg.barrier()  # (torch.cuda.synchronize: both streams)
+    dt = max_over_ranks(rt, time.perf_counter() - t0)
+    same = all(bool(torch.equal(t["counts"], leg.counts)) and bool(torch.equal(t["z"].view(torch.int32), leg.z.view(torch.int32)))
+               for t in sets)
+    ref = leg.pwms if args.em_fast == 2 else None  # (the main leg's last EM ran in the bit-exact mode when that is the step's mode)
+    if ref is not None:
+        same = same and all(bool(torch.equal(t["pwms"].view(torch.int32), ref.view(torch.int32))) for t in sets)
+    ctx2.close()
+    ms = dt / steps * 1e3
+    return {"ms_per_step": round(ms, 4), "gbp_per_s": round(args.nseq * args.L * rt.world / (ms * 1e-3) / 1e9, 3), "steps": steps,
+            "same_bits_as_the_sequential_passes": same,
+            "what": "throughput of the same passes as a two-stream pipeline over independent batches: the EM of batch i beside the count "
+                    "of batch i + 1 (second context and stream, two sets of tables); NOT the line's value, which runs one pass after the other"}
 
 
 def config3_leg(rt, args):
@@ -502,6 +572,7 @@ def main():
         acc, dt, exchange, step, seed_pwms = leg.acc, leg.dt, leg.exchange, leg.step, leg.seed_pwms
         checks, checks_ok = leg.checks, leg.checks_ok
         ltot_global, n_items = int(scal[84].item()), int(ni.value)
+        pipelined = pipelined_leg(rt, args, leg, W, both, args.steps, max(2, args.warmup)) if args.pipelined else None
 
         def time_em(mode, n, init, out, state, change, reps=2):
             if not n:
@@ -680,6 +751,8 @@ def main():
         # tables add up to for this (W, size, N) -- at every N, so that a multi-GPU line verifies itself
         out["checks"] = checks
         out["checks_ok"] = checks_ok
+        if pipelined is not None:
+            out["components"]["pipelined"] = pipelined
         if config3 is not None:
             out["components"]["config3"] = config3
         if config4 is not None:

@@ -51,6 +51,8 @@ def test_single_rank_json_contract():
     assert d["checks_ok"]["ok"] is None
     c3 = d["components"]["config3"]
     assert c3["ltot_global"] == 50000 * 189 and c3["count_ms"] > 0 and c3["exchange_bytes"] == 4 * 4 ** 12 + 680 and c3["checks_ok"]["ok"] is None
+    pl = d["components"]["pipelined"]  # the same passes as a two-stream pipeline: an extra throughput figure, same bits
+    assert pl["same_bits_as_the_sequential_passes"] is True and pl["ms_per_step"] > 0 and pl["steps"] == 2
     c4 = d["components"]["config4"]
     assert c4["pwms"] == 32 and c4["split_equals_1rank_bit_for_bit"] is True and c4["ms_split"]["serial"] > 0 and c4["allgather_ms"] >= 0
     # the compiled reference on the same file, same box, same run: the denominator of the end-to-end ratio -- and its
@@ -81,6 +83,7 @@ def test_two_rank_rehearsal_allreduces_the_tables():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
     assert d["config"]["ltot_global"] == 2 * 150000 * 191  # both shards arrived in the reduced ltot
     assert abs(d["value"] - 2 * 150000 * 200 / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-2 * d["value"]
+    assert d["components"]["pipelined"]["same_bits_as_the_sequential_passes"] is True  # (also with the exchange step inside)
     c4 = d["components"]["config4"]  # 8 stress PWMs dealt to two ranks, gathered, equal to all 8 on one rank
     assert c4["n_gpus"] == 2 and c4["split_equals_1rank_bit_for_bit"] is True
 
