@@ -261,7 +261,7 @@ std::vector<size_t> BasePattern::select_base_patterns(const float zscore_thresho
                                                       bool single_stranded, bool filter_neighbors) {
   std::vector<size_t> selected;
   std::vector<char> seen(number_patterns, 0);
-  std::vector<ranked_prefix::Entry> order;
+  ranked_prefix::EntryVec order;
   size_t n_ranked = 0;
   static const bool on_device = [] {
     const char* e = std::getenv("PENGK_SEED_SELECT");

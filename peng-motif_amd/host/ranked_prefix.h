@@ -18,6 +18,9 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <memory>
+#include <new>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -33,6 +36,9 @@ struct Entry {
 
 // the comparator of sort_indices (src/base_pattern.h:166-172): descending z
 inline bool before(const Entry& a, const Entry& b) { return a.z > b.z; }
+
+typedef std::vector<Entry> EntryVec;  // (transparent huge pages for it were tried: no gain on the GPU box's host, and the
+// threaded partitions ran five times SLOWER on them in the build container; profiles/r04_rank_bench.log)
 
 namespace detail {
 
@@ -66,6 +72,127 @@ inline Entry* partition(Entry* first, Entry* last, const Entry* pivot) {
   }
 }
 
+// The same partition, by several threads, for the large ranges at the top of the replay (the first three or four
+// partitions are ~90 % of its work: 16.7 M entries at W = 12).  The scalar loop above pairs the k-th "left stopper" --
+// the k-th element from the left that is NOT before the pivot -- with the k-th "right stopper" -- the k-th element from
+// the right that the pivot is NOT before --, swaps them and goes on until the two meet; a swapped element is never looked
+// at again (both scans have passed it), so the pairs are those of the ORIGINAL array: stoppers can be listed first, by
+// chunks, then the crossing K = the first k with L_k >= R_k is found (L ascends, R descends), the K pairs are swapped in
+// any order, and the result -- the arrangement, and the return value (where the left scan stops last: L_K, or R_(K-1) if
+// that comes first, see below) -- is the scalar loop's, element for element
+// (host/tests/ranked_prefix_test.cpp runs both against std::sort on tie-heavy arrays of up to 2^22 entries).
+inline Entry* partition_parallel(Entry* first, Entry* last, const Entry* pivot, unsigned nt) {
+  const size_t n = (size_t)(last - first);
+  const float pz = pivot->z;
+  // stopper lists per chunk, in uninitialised storage (a vector would zero-fill what is overwritten at once)
+  struct List {
+    std::unique_ptr<uint32_t[]> p;
+    size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    uint32_t operator[](size_t i) const { return p[i]; }
+  };
+  std::vector<List> Ls(nt), Rs(nt);
+  {
+    auto scan = [&](unsigned t) {
+      const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+      uint32_t* l = new uint32_t[hi - lo + 1];
+      uint32_t* r = new uint32_t[hi - lo + 1];
+      size_t nl = 0, nr = 0;
+      for (size_t i = lo; i < hi; ++i) {  // (branch-free appends: a random table mispredicts every other compare)
+        const float zi = first[i].z;
+        l[nl] = (uint32_t)i;
+        nl += !(zi > pz);
+        r[nr] = (uint32_t)i;
+        nr += !(pz > zi);
+      }
+      Ls[t].p.reset(l);
+      Ls[t].n = nl;
+      Rs[t].p.reset(r);
+      Rs[t].n = nr;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(scan, t);
+    scan(0);
+    for (auto& x : th) x.join();
+  }
+  std::vector<size_t> preL(nt + 1, 0), preR(nt + 1, 0);  // stoppers in the chunks in front of chunk t
+  for (unsigned t = 0; t < nt; ++t) {
+    preL[t + 1] = preL[t] + Ls[t].size();
+    preR[t + 1] = preR[t] + Rs[t].size();
+  }
+  const size_t totL = preL[nt], totR = preR[nt];
+  auto Lk = [&](size_t k) {  // position of the k-th left stopper
+    const unsigned t = (unsigned)(std::upper_bound(preL.begin(), preL.end(), k) - preL.begin()) - 1u;
+    return (size_t)Ls[t][k - preL[t]];
+  };
+  auto Rk = [&](size_t k) {  // position of the k-th right stopper counted from the right
+    const size_t a = totR - 1 - k;  // its ascending rank
+    const unsigned t = (unsigned)(std::upper_bound(preR.begin(), preR.end(), a) - preR.begin()) - 1u;
+    return (size_t)Rs[t][a - preR[t]];
+  };
+  // K = the first k with L_k >= R_k.  (The median-of-three pivot guarantees the scalar loop a stopper on either side
+  // before it leaves the range; should the lists end first, the range is handed to the scalar loop untouched.)
+  const size_t kmax = std::min(totL, totR);
+  size_t lo = 0, hi = kmax;
+  while (lo < hi) {
+    const size_t mid = lo + (hi - lo) / 2;
+    if (Lk(mid) >= Rk(mid)) hi = mid;
+    else lo = mid + 1;
+  }
+  const size_t K = lo;  // (at k = kmax one of the lists has ended: the pointers have met by then at the latest)
+  // Where the left scan stops in its last round: at L_K -- or earlier, at R_(K-1), which now holds what the last swap
+  // brought over from the left, a left stopper by definition (in the ORIGINAL array that place need not be one).
+  if (K == 0 && totL == 0) return partition(first, last, pivot);  // (cannot happen behind a median-of-three pivot)
+  size_t cut = K < totL ? Lk(K) : n;
+  if (K > 0) cut = std::min(cut, Rk(K - 1));
+  {
+    auto swaps = [&](unsigned t) {
+      size_t k = K * t / nt;
+      const size_t k1 = K * (t + 1) / nt;
+      if (k >= k1) return;
+      unsigned tl = (unsigned)(std::upper_bound(preL.begin(), preL.end(), k) - preL.begin()) - 1u;
+      size_t il = k - preL[tl];
+      size_t a = totR - 1 - k;
+      unsigned tr = (unsigned)(std::upper_bound(preR.begin(), preR.end(), a) - preR.begin()) - 1u;
+      size_t ir = a - preR[tr];
+      for (; k < k1; ++k) {
+        std::swap(first[Ls[tl][il]], first[Rs[tr][ir]]);
+        if (++il == Ls[tl].size()) {
+          il = 0;
+          do ++tl;
+          while (tl < nt && Ls[tl].empty());
+        }
+        if (ir == 0) {
+          do --tr;
+          while (tr != (unsigned)-1 && Rs[tr].empty());
+          ir = tr != (unsigned)-1 ? Rs[tr].size() - 1 : 0;
+        } else {
+          --ir;
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(swaps, t);
+    swaps(0);
+    for (auto& x : th) x.join();
+  }
+  return first + cut;
+}
+
+// Ranges from 2^18 entries on are partitioned by several threads, one per 2^17 entries and 16 at most (on the GPU box's
+// host 1 M entries rank in 7.9 ms on one thread, 4.6 on 8, 7.2 on 16, 14 on 32; 16.7 M in 71 / 22 / 17 / 16 ms:
+// profiles/r04_rank_bench.log).  PENGK_RANK_THREADS caps the number (1 = the scalar loop everywhere).
+inline unsigned partition_threads(size_t n) {
+  static const unsigned cap = [] {
+    const char* e = std::getenv("PENGK_RANK_THREADS");
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return e && *e ? (unsigned)std::max(1, std::atoi(e)) : std::min(16u, hw);
+  }();
+  if (n < ((size_t)1 << 18) || n >= ((size_t)1 << 31)) return 1u;
+  return (unsigned)std::min<size_t>(cap, n >> 17);
+}
+
 inline void quick_loop(Entry* first, Entry* last, long depth, float threshold, Entry*& ranked_end) {
   while (last - first > kChunk) {
     if (depth == 0) {
@@ -75,7 +202,8 @@ inline void quick_loop(Entry* first, Entry* last, long depth, float threshold, E
     --depth;
     Entry* mid = first + (last - first) / 2;
     median_to_first(first, first + 1, mid, last - 1);
-    Entry* cut = partition(first + 1, last, first);
+    const unsigned nt = partition_threads((size_t)(last - first));
+    Entry* cut = nt > 1 ? partition_parallel(first + 1, last, first, nt) : partition(first + 1, last, first);
     if (first->z < threshold) {
       // [cut, last) holds only z <= pivot < threshold, and so does everything to its right: never read
       if (cut < ranked_end) ranked_end = cut;
@@ -114,12 +242,12 @@ inline void insertion(Entry* first, Entry* last) {
 
 // Ranks ids 0..n-1 by z.  On return entries[0 .. n_ranked) equal the first n_ranked elements of
 // std::sort(ids, sort_indices(z)); n_ranked == n, or every id ranked at or after n_ranked has z < threshold.
-inline size_t rank(const float* z, size_t n, float threshold, std::vector<Entry>& entries) {
+inline size_t rank(const float* z, size_t n, float threshold, EntryVec& entries) {
   entries.resize(n);
   bool ordered = true;  // a NaN breaks the "right of the pivot is smaller" argument: sort everything then
   {
     // 4^12 entries are 134 MB: filled by several threads (the replay itself is sequential by nature)
-    unsigned nt = n < ((size_t)1 << 22) ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned nt = n < ((size_t)1 << 18) ? 1u : std::min(n < ((size_t)1 << 22) ? 4u : 16u, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<char> nan(nt, 0);
     Entry* e = entries.data();
     auto fill = [&](unsigned t) {

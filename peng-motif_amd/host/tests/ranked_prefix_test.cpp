@@ -21,7 +21,7 @@ int check(const std::vector<float>& z, float thr, const char* what) {
   std::vector<size_t> order(n);
   for (size_t i = 0; i < n; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), by_z{z.data()});
-  std::vector<ranked_prefix::Entry> e;
+  ranked_prefix::EntryVec e;
   const size_t m = ranked_prefix::rank(z.data(), n, thr, e);
   if (m > n) {
     printf("FAIL %s: prefix %zu > n %zu\n", what, m, n);
@@ -47,7 +47,8 @@ int check(const std::vector<float>& z, float thr, const char* what) {
 int main() {
   std::mt19937_64 rng(12345);
   int cases = 0;
-  const size_t sizes[] = {0, 1, 2, 15, 16, 17, 18, 33, 100, 1000, 4096, 65536, 300001, 1u << 20};
+  // (from 2^17 entries on the large partitions run on several threads: ranked_prefix.h, partition_parallel)
+  const size_t sizes[] = {0, 1, 2, 15, 16, 17, 18, 33, 100, 1000, 4096, 65536, 131071, 131072, 131073, 300001, 1u << 20, (1u << 22) + 5};
   for (size_t n : sizes) {
     for (int style = 0; style < 6; ++style) {
       std::vector<float> z(n);
@@ -77,7 +78,7 @@ int main() {
     z[4000] = INFINITY;
     if (check(z, 10.f, "inf")) return 1;
     z[123] = NAN;
-    std::vector<ranked_prefix::Entry> e;
+    ranked_prefix::EntryVec e;
     if (ranked_prefix::rank(z.data(), z.size(), 10.f, e) != z.size()) {
       printf("FAIL nan: prefix must be the whole array\n");
       return 1;
