@@ -46,6 +46,7 @@ def test_single_rank_json_contract():
     # the spread is on the line: every run's wall time, the median as wall_s, where the runtime's start and the exit go
     assert len(e2e["walls_s"]) == 3 and min(e2e["walls_s"]) <= e2e["wall_s"] <= max(e2e["walls_s"]) and e2e["best_wall_s"] == min(e2e["walls_s"])
     assert e2e["exit_s"] is not None and e2e["exit_s"] >= 0 and any("runtime start" in k for k in e2e["runtime_start_ms"])
+    assert 2 <= len(e2e["device_ready_probe_first_stream_ms"]) <= 12  # (untimed probe runs until the box answers normally)
     # the exchange step has its own events; the checks are always on the line (no reference-derived row at this toy size)
     assert d["components"]["exchange_ms"] >= 0 and set(d["checks"]) == {"sha_counts", "sha_z", "sha_bg_ltot", "sha_em_pwms"}
     assert d["checks_ok"]["ok"] is None
