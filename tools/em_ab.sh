@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/em_ab.sh ROUNDS "ENV_A" "ENV_B" ... -> tools/em_probe.py (16 PWMs, 1000 PWMs, W = 12) under each environment
-# in turn (e.g. "PENGK_LIB=$PWD/ablation_libs/x.so PENGK_EM_STAGGER=1"), medians per environment and case
+# in turn (e.g. "PENGK_LIB=$PWD/ablation_libs/x.so"), medians per environment and case
 R=$1; shift
 for r in $(seq 1 $R); do
   for envs in "$@"; do
