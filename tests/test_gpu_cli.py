@@ -249,3 +249,24 @@ def test_pattern_lengths_beyond_the_tables_end_like_the_references_too_long(tmp_
     assert r.returncode == 1 and b"Warning: pattern length too long!" in r.stderr and b"max pattern length: 14" in r.stderr
     r = subprocess.run([cli, fa, "-w", "18"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 1 and b"Warning: pattern length too long!" in r.stderr and b"max pattern length: 31" in r.stderr
+
+
+@pytest.mark.parametrize("flags", [["-w", "2"], ["-w", "2", "--bg-model-order", "0", "-t", "2", "--count-threshold", "1"],
+                                   ["-w", "2", "--strand", "PLUS", "--bg-model-order", "0", "-t", "1", "--no-em"]],
+                         ids=["w2", "w2_bg0", "w2_plus_bg0_noem"])
+@pytest.mark.parametrize("text", [b"", b">a\n>b\n", b">a\nA\n>b\nAC\n", b">a\nNNNNNNNNNNNN\n>b\nNANANANANA\n",
+                                  b">a\nACGTACGTTTGACCA\n>b\nacgtnACGTNNacgggt\n>c\nTTTTTTTTTTTTTTTTTTTTTTTTT\n"],
+                         ids=["empty", "headers_only", "too_short", "mostly_n", "tiny"])
+def test_w2_on_degenerate_inputs_against_reference_binary(tmp_path, text, flags):
+    """W = 2, the shortest pattern length the reference accepts (/root/reference/src/Global.cpp:103-106), on inputs without
+    records, without a window, with more N than bases: exit code, stdout and MEME of both programs byte for byte."""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/peng_motif_ref not present (the reference is only built in the build container)")
+    fa = tmp_path / "d.fa"
+    fa.write_bytes(text)
+    outs = []
+    for tag, exe in (("ref", REF_CLI), ("here", CLI)):
+        meme = tmp_path / (tag + ".meme")
+        r = subprocess.run([exe, str(fa)] + flags + ["-o", str(meme)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        outs.append((r.returncode, r.stdout, meme.read_bytes() if meme.exists() else None))
+    assert outs[0] == outs[1], (outs[0][0], outs[1][0], outs[0][1][-300:], outs[1][1][-300:])
