@@ -808,7 +808,7 @@ __device__ __forceinline__ bool lean_div_ok(float a_lo, float a_hi, float b_lo, 
 // The ranges of one PWM's three divisions (src/peng.cpp:124-125, 180-197): odds = pr / bg, t = s / odds,
 // w = (c s) / (1 + t).  bg_range = {min, max} of the background table as float bits (em_bg_range_kernel).
 template <int W>
-__device__ __forceinline__ bool lean_ranges_ok(const float* s_pwm, const uint32_t* bg_range, float saturation) {
+__device__ __forceinline__ bool lean_ranges_ok(const float* s_pwm, uint32_t bg_lo_bits, uint32_t bg_hi_bits, float saturation) {
   float p_lo = 1.0f, p_hi = 1.0f;
   for (int p = 0; p < W; ++p) {
     const float a = s_pwm[p * 4], b = s_pwm[p * 4 + 1], c = s_pwm[p * 4 + 2], d = s_pwm[p * 4 + 3];
@@ -819,8 +819,8 @@ __device__ __forceinline__ bool lean_ranges_ok(const float* s_pwm, const uint32_
   // (products round: half a unit in the last place per factor, far inside the factor of two below)
   p_lo *= 0.5f;
   p_hi *= 2.0f;
-  const float b_lo = __uint_as_float(bg_range[0]), b_hi = __uint_as_float(bg_range[1]);
-  if (bg_range[1] > 0x7F7FFFFFu || !(saturation > 0.0f)) return false;  // a negative or non-finite background entry
+  const float b_lo = __uint_as_float(bg_lo_bits), b_hi = __uint_as_float(bg_hi_bits);
+  if (bg_hi_bits > 0x7F7FFFFFu || !(saturation > 0.0f)) return false;  // a negative or non-finite background entry
   if (!lean_div_ok(p_lo, p_hi, b_lo, b_hi)) return false;
   const float o_lo = p_lo / b_hi * 0.5f, o_hi = p_hi / b_lo * 2.0f;  // odds
   if (!lean_div_ok(saturation, saturation, o_lo, o_hi)) return false;
@@ -915,14 +915,22 @@ __global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __res
                                                               float* __restrict__ sums, const uint32_t* __restrict__ bg_range) {
   using G = BlockGeo<W>;
   const uint32_t pw = blockIdx.y, sp = blockIdx.x;
-  if (state[2 * pw + 1] == 0) return;
   __shared__ float s_pwm[W * 4];
   __shared__ float part[4][28];
   __shared__ uint32_t s_lean;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  if (t < W * 4) s_pwm[t] = pwms[(size_t)pw * W * 4 + t];
+  // (the "still running" flag, the PWM and the background's range are asked for TOGETHER -- one memory round trip in front
+  // of the span instead of three, in a kernel of ~20 us; the PWM is used before the flag is looked at for that)
+  int32_t running = state[2 * pw + 1];
+  float mine = pwms[(size_t)pw * W * 4 + (t < W * 4 ? t : 0u)];
+  uint32_t bg_lo = bg_range[0], bg_hi = bg_range[1];
+  // (one place where all four are needed, in front of the branch: left to itself the compiler asks for the flag, waits,
+  // branches, asks for the next ...)
+  asm volatile("" : "+s"(running), "+v"(mine), "+s"(bg_lo), "+s"(bg_hi));
+  if (t < W * 4) s_pwm[t] = mine;
+  if (running == 0) return;
   __syncthreads();
-  if (t == 0) s_lean = lean_ranges_ok<W>(s_pwm, bg_range, saturation) ? 1u : 0u;  // (workgroup-uniform: one PWM, one table)
+  if (t == 0) s_lean = lean_ranges_ok<W>(s_pwm, bg_lo, bg_hi, saturation) ? 1u : 0u;  // (workgroup-uniform: one PWM, one table)
   __syncthreads();
   const bool lean = s_lean != 0u;
   float* out = wbuf + (size_t)pw * G::NP + (size_t)sp * 16384u;
@@ -1166,7 +1174,20 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
   }
   const uint32_t sl = lin - extra_wgs, slot = sl >> 3;
   const uint32_t pw = (sl & 7u) + 8u * (slot / G::SPANS), sp = slot % G::SPANS;
-  if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
+  if (pw >= n_pwm) return;
+  // The span's 64 KiB are asked for FIRST, together with the PWM's flags; the estimates below (another round trip: the
+  // cells' block sums) are worked out while the span is on its way.
+  constexpr uint32_t T = 64u * SPAN_EVAL_WAVES, PER = 4096u / T;
+  seqsum::f4 v[PER];
+  {
+    const seqsum::f4* src = reinterpret_cast<const seqsum::f4*>(wbuf + (size_t)pw * G::NP + (size_t)sp * 16384u);
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) v[k] = src[t + T * k];
+  }
+  // (the flags are looked at behind the estimates -- which touch nothing but this workgroup's LDS -- so that no branch
+  // stands between the span's loads and the estimates' loads: a workgroup of a PWM that is done leaves a little later)
+  const int32_t running = state[2 * pw + 1];
+  const uint32_t flagged = bad[pw];
   constexpr uint32_t TASKS = (G::CELLS + SPAN_EVAL_WAVES - 1u) / SPAN_EVAL_WAVES;  // per wave
   seqsum::BlockRecord* cells = rec + (size_t)pw * G::CELLS * G::NBLK;
   // task (p, j) of the span -> its cell and block
@@ -1196,13 +1217,9 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
       }
     }
   }
+  if (running == 0 || flagged) return;
   {
-    constexpr uint32_t T = 64u * SPAN_EVAL_WAVES, PER = 4096u / T;
-    const seqsum::f4* src = reinterpret_cast<const seqsum::f4*>(wbuf + (size_t)pw * G::NP + (size_t)sp * 16384u);
     seqsum::f4* dst = reinterpret_cast<seqsum::f4*>(span);
-    seqsum::f4 v[PER];
-#pragma unroll
-    for (uint32_t k = 0; k < PER; ++k) v[k] = src[t + T * k];
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
       const uint32_t idx = t + T * k;
@@ -1244,22 +1261,31 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
   using G = BlockGeo<W>;
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
-  if (pw >= n_pwm || state[2 * pw + 1] == 0) return;
+  if (pw >= n_pwm) return;
   __shared__ __attribute__((aligned(16))) float lds[seqsum::WALK_LDS_FLOATS];
   seqsum::WalkCounts wc;
   const uint32_t lane = threadIdx.x;
   const seqsum::BlockRecord* r = rec + ((size_t)pw * G::CELLS + cell) * G::NBLK;
+  // (the PWM's two flags and the chain's first 64 records are asked for together: one memory round trip at the head of
+  // every chain -- the kernel ends with its longest one -- instead of three)
+  int32_t running = state[2 * pw + 1];
+  uint32_t flagged = bad[pw];
+  uint4 first = reinterpret_cast<const uint4*>(r)[lane];
+  // (one place where all of them are needed, in front of the branch: left to itself the compiler asks for a flag, waits,
+  // branches, asks for the next ...)
+  asm volatile("" : "+s"(running), "+s"(flagged), "+v"(first.x), "+v"(first.y), "+v"(first.z), "+v"(first.w));
+  if (running == 0) return;
   float s = 0.0f;
   const float* w = wbuf + (size_t)pw * G::NP;  // (no second copy in position 0's order: few blocks are read here)
-  if (bad[pw]) {  // (a flagged PWM: summed by finalize_pwm's plain loop)
+  if (flagged) {  // (a flagged PWM: summed by finalize_pwm's plain loop)
   } else if ((cell >> 2) == 0u) {
     EmTerms0<W> src0{w, cell & 3u};
     src0.bind_stage(lane);
-    s = seqsum::walk_chain(src0, r, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
+    s = seqsum::walk_chain(src0, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
   } else {
     EmTerms<W> src{w, cell >> 2, cell & 3u};
     src.bind_stage(lane);
-    s = seqsum::walk_chain(src, r, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
+    s = seqsum::walk_chain(src, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
   }
   // the PWM's last cell to arrive does what em_finalize_kernel does (one launch less per iteration)
   // No fences (a device-scope release writes the XCD's whole L2 back): the sum is stored by a device-scope atomic, which

@@ -328,7 +328,8 @@ struct BlockRecord {
   uint32_t pad;
 };
 
-// The chain of a cell over evaluated blocks (one wave).  rec[b] as block_increments left it; n_blocks is a multiple of 64.
+// The chain of a cell over evaluated blocks (one wave).  rec[b] as block_increments left it; n_blocks is a multiple of 64;
+// first_records = rec[lane] (the caller loads it beside its own flags).
 // The blocks without a binade come from the table, through LDS: Source::stage(b, lane, buf) asks for block b with loads
 // that write LDS directly (16 KiB, rows of 256 bytes, Row::read_staged).  No register waits for them, so TWO blocks are
 // on their way at any time and the wait for the earlier one is `s_waitcnt vmcnt(loads of the later one)`: walking the
@@ -361,8 +362,8 @@ struct WalkCounts {
   uint32_t fetched = 0, mispredicted = 0, restaged = 0, restaged_waits = 0;
 };
 template <class Source>
-__device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord* __restrict__ rec, uint32_t n_blocks, lds_float* lds,
-                                            uint32_t lane, WalkCounts& wc) {
+__device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord* __restrict__ rec, const uint4& first_records,
+                                            uint32_t n_blocks, lds_float* lds, uint32_t lane, WalkCounts& wc) {
   Stats st;
   const unsigned long long w0 = PENGK_CLOCK();
   float s = 0.0f;
@@ -373,7 +374,8 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
   bool restaged = false;                    // that one was asked for again after the other: the counted wait does not cover it
 #pragma unroll 1
   for (uint32_t base = 0; base < n_blocks; base += 64u) {
-    const uint4 r = reinterpret_cast<const uint4*>(rec)[base + lane];
+    // (first_records = this lane's record of the first chunk, loaded by the caller together with what else it needs)
+    const uint4 r = base == 0u ? first_records : reinterpret_cast<const uint4*>(rec)[base + lane];
     const unsigned long long open = __builtin_amdgcn_ballot_w64(r.x == NO_BINADE);
     auto open_after = [&](uint32_t b) {  // the next block of this chunk without a binade behind block b, or NO_BINADE
       const uint32_t j = b - base;
