@@ -1393,6 +1393,24 @@ namespace {
 // weights, was measured: 0.99 ms -- a chain's 32 KiB of LDS per wave halve the evaluation kernel's workgroups per CU.)
 // (PWMs are independent; every batch has its own tables, records and sums.)  `budget` = bytes of weight tables in flight.
 constexpr int EM_COUNTERS = 4;  // fetched, mispredicted, restaged, restaged_waits (seqsum::WalkCounts); behind them: the background table's {min, max}
+// What a pengk_em call in this mode starts from, in ONE launch (four to five memsets took 8-25 us apiece in front of the
+// first weights kernel): the chains' counters zero, the background's range {all ones, 0} for em_bg_range_kernel's min /
+// max -- or {0, all ones}, a range nothing accepts, with the lean division off --, every lane's flags and arrival
+// counters zero.
+__global__ __launch_bounds__(256) void em_ahead_setup_kernel(unsigned long long* __restrict__ counters, uint32_t* __restrict__ bg_range,
+                                                             uint32_t lean, char* __restrict__ partials, size_t partials_b, size_t flags_at,
+                                                             uint32_t flag_words, uint32_t lanes) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t < (uint32_t)EM_COUNTERS) counters[t] = 0ull;
+  if (t == 0) {
+    bg_range[0] = lean ? 0xFFFFFFFFu : 0u;
+    bg_range[1] = lean ? 0u : 0xFFFFFFFFu;
+  }
+  for (uint32_t l = 0; l < lanes; ++l) {
+    uint32_t* f = reinterpret_cast<uint32_t*>(partials + l * partials_b + flags_at);
+    for (uint32_t i = t; i < flag_words; i += gridDim.x * 256u) f[i] = 0u;
+  }
+}
 template <int W>
 int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
                         const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change, size_t budget) {
@@ -1424,14 +1442,13 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes, lanes * blocks_b);
   if (rc) return rc;
   if (!ctx->d_em_counters) PENGK_HIP(hipMalloc((void**)&ctx->d_em_counters, (EM_COUNTERS + 1) * sizeof(unsigned long long)));
-  PENGK_HIP(hipMemsetAsync(ctx->d_em_counters, 0, EM_COUNTERS * sizeof(unsigned long long), ctx->stream));  // per pengk_em call
   // the range of the background table, for the weights kernel's choice of division (lean_ranges_ok)
   uint32_t* bg_range = reinterpret_cast<uint32_t*>(ctx->d_em_counters + EM_COUNTERS);
   {
-    // {min, max} start as {all ones, 0}; with the option off they stay {0, all ones}: a range nothing accepts
-    // (two 32-bit fills, no host buffer that would have to outlive an asynchronous copy)
-    PENGK_HIP(hipMemsetD32Async((hipDeviceptr_t)bg_range, ctx->em_lean_div ? (int)0xFFFFFFFFu : 0, 1, ctx->stream));
-    PENGK_HIP(hipMemsetD32Async((hipDeviceptr_t)(bg_range + 1), ctx->em_lean_div ? 0 : (int)0xFFFFFFFFu, 1, ctx->stream));
+    const uint32_t flag_words = (uint32_t)(2 * batch);  // (batch <= 65528)
+    hipLaunchKernelGGL(em_ahead_setup_kernel, dim3((flag_words + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->d_em_counters, bg_range,
+                       ctx->em_lean_div ? 1u : 0u, reinterpret_cast<char*>(ctx->d_em_partials), partials_b, flags_at, flag_words,
+                       (uint32_t)lanes);
     if (ctx->em_lean_div)
       hipLaunchKernelGGL(em_bg_range_kernel, dim3(32), dim3(1024), 0, ctx->stream, d_bg, (uint32_t)np, bg_range);  // (np = 4^W: a multiple of 4)
   }
@@ -1443,43 +1460,46 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
     streams[l] = ctx->em_streams[l - 1];
   }
   if (lanes > 1 && !ctx->em_fork) PENGK_HIP(hipEventCreateWithFlags(&ctx->em_fork, hipEventDisableTiming));
-  for (int l = 0; l < lanes; ++l)
-    PENGK_HIP(hipMemsetAsync(reinterpret_cast<char*>(ctx->d_em_partials) + l * partials_b + flags_at, 0, (size_t)2 * batch * sizeof(uint32_t),
-                             ctx->stream));
   if (lanes > 1) {  // (everything enqueued so far -- the tables' producers, em_init_kernel -- comes first on all of them)
     PENGK_HIP(hipEventRecord(ctx->em_fork, ctx->stream));
     for (int l = 1; l < lanes; ++l) PENGK_HIP(hipStreamWaitEvent(streams[l], ctx->em_fork, 0));
   }
   // Once the lanes are forked they are ALWAYS joined, also when a launch fails half way: the caller reads and frees
   // buffers on ctx->stream, and kernels may still run on the other streams.
+  // The batches go to the lanes in turn, and the launches are ENQUEUED in turn as well: iteration 1 of every lane's batch,
+  // then iteration 2 ...  Batch by batch -- all iterations of lane 0's, then all of lane 1's -- the second lane got its
+  // first kernel only when the host had enqueued the first lane's thirty launches: with 16 PWMs the first lane was two
+  // thirds through its ten iterations by then (profiles/r04_em_kernels.log, the timeline).
   const int rc_launch = [&]() -> int {
-    int64_t chunk = 0;
-    for (int64_t first = 0; first < n_pwm; first += batch, ++chunk) {
-      const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
-      const int l = (int)(chunk % lanes);
-      hipStream_t st = streams[l];
-      float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_tables) + l * tables_b);
-      double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->d_em_partials) + l * partials_b);
-      uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(partials) + flags_at);
-      uint32_t* done = bad + batch;
-      float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * blocks_b);
-      seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
+    for (int64_t round0 = 0; round0 < n_pwm; round0 += batch * lanes) {
       for (int it = 0; it < max_it; ++it) {
-        hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
-                           d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums, (const uint32_t*)bg_range);
-        if (!B::PREDICT_IN_EVAL)
-          hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec,
-                             (uint32_t)ctx->em_test_skew);
-        const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
-        const uint64_t extra_wgs = (uint64_t)groups * ((B::CELLS + 3) / 4);  // block 0 of every cell, in front of ...
-        const uint64_t wgs = extra_wgs + (uint64_t)groups * B::SPANS;         // ... the spans
-        const unsigned gx = 1024u;
-        hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
-                           d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums, (uint32_t)ctx->em_test_skew,
-                           (uint32_t)extra_wgs);
-        hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, d_state + 2 * first, (const float*)tables,
-                           (const seqsum::BlockRecord*)rec, partials, bad, (uint32_t)nb, done, d_pwms + (size_t)first * W * 4,
-                           d_change + first, threshold, max_it, ctx->d_em_counters);
+        for (int l = 0; l < lanes; ++l) {
+          const int64_t first = round0 + (int64_t)l * batch;
+          if (first >= n_pwm) break;
+          const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
+          hipStream_t st = streams[l];
+          float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_tables) + l * tables_b);
+          double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->d_em_partials) + l * partials_b);
+          uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(partials) + flags_at);
+          uint32_t* done = bad + batch;
+          float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * blocks_b);
+          seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
+          hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
+                             d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums, (const uint32_t*)bg_range);
+          if (!B::PREDICT_IN_EVAL)
+            hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec,
+                               (uint32_t)ctx->em_test_skew);
+          const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
+          const uint64_t extra_wgs = (uint64_t)groups * ((B::CELLS + 3) / 4);  // block 0 of every cell, in front of ...
+          const uint64_t wgs = extra_wgs + (uint64_t)groups * B::SPANS;         // ... the spans
+          const unsigned gx = 1024u;
+          hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
+                             d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums, (uint32_t)ctx->em_test_skew,
+                             (uint32_t)extra_wgs);
+          hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, d_state + 2 * first, (const float*)tables,
+                             (const seqsum::BlockRecord*)rec, partials, bad, (uint32_t)nb, done, d_pwms + (size_t)first * W * 4,
+                             d_change + first, threshold, max_it, ctx->d_em_counters);
+        }
       }
       PENGK_HIP(hipGetLastError());
     }
