@@ -1195,7 +1195,9 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
   auto block_of = [&](uint32_t task) { return (task >> 2) <= 6u ? sp : G::high_block(task >> 2, sp, task & 3u); };
   // the binades of this wave's blocks: the estimate in front of / behind a block from the cell's block sums
   // (block_binade), or what em_block_predict_kernel left in the record
-  __shared__ uint32_t binade[TASKS][SPAN_EVAL_WAVES];
+  // (kept in a register, lane i = this wave's i-th block: with nothing in LDS beside the span a workgroup takes exactly
+  // 64 KiB, and two of them fit a CU's 160 KiB beside a chain workgroup's 32 KiB of the other lane -- 1 % on every EM figure)
+  uint32_t binades = seqsum::NO_BINADE;
 #pragma unroll 1
   for (uint32_t i = 0; i < TASKS; ++i) {
     const uint32_t task = wave + SPAN_EVAL_WAVES * i;
@@ -1211,9 +1213,11 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
         }
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
-        if (lane == 0) binade[i][wave] = block_binade((double)acc, (double)acc + (double)cs[b], skew, cell * G::NBLK + b);
+        const uint32_t e = block_binade((double)acc, (double)acc + (double)cs[b], skew, cell * G::NBLK + b);  // (the same in all lanes)
+        if (lane == i) binades = e;
       } else {
-        if (lane == 0) binade[i][wave] = cells[(size_t)cell * G::NBLK + b].e;
+        const uint32_t e = cells[(size_t)cell * G::NBLK + b].e;
+        if (lane == i) binades = e;
       }
     }
   }
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
     const uint32_t p = task >> 2, j = task & 3u;
     if (block_of(task) == 0u) continue;  // (folded from zero by the workgroups behind the spans)
     seqsum::BlockRecord* r = cells + (size_t)cell_of(task) * G::NBLK + block_of(task);
-    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)binade[i][wave]);
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)binades, (int)i);
     if (e == seqsum::NO_BINADE) {
       if (G::PREDICT_IN_EVAL && lane == 0) r->e = seqsum::NO_BINADE;
       continue;
