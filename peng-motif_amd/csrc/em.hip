@@ -1392,9 +1392,10 @@ namespace {
 // PWMs go round in batches, and the batches take turns on the context's stream and up to three more.  A batch's iteration
 // is weights -> block evaluation -> chains, the first two bound by arithmetic and the last by one wave per cell waiting
 // for its next block; with several batches in flight the waits of one are filled by the others.  (Left to themselves the
-// lanes fall into step -- chains beside chains, weights beside weights: 0.89 ms for 16 PWMs x 10 iterations at W = 10
-// against 0.96 on one stream.  Starting the second lane when the first one's chains start, so that chains run beside
-// weights, was measured: 0.99 ms -- a chain's 32 KiB of LDS per wave halve the evaluation kernel's workgroups per CU.)
+// lanes fall into step -- chains beside chains, weights beside weights: 0.83 ms for 16 PWMs x 10 iterations at W = 10
+// against 0.92 on one stream.  Holding the second lane back until the first one's first weights / evaluation / chain
+// kernel has run, so that chains run beside weights, was measured twice: no gain, behind the chains a loss --
+// profiles/r04_em_kernels.log.)
 // (PWMs are independent; every batch has its own tables, records and sums.)  `budget` = bytes of weight tables in flight.
 constexpr int EM_COUNTERS = 4;  // fetched, mispredicted, restaged, restaged_waits (seqsum::WalkCounts); behind them: the background table's {min, max}
 // What a pengk_em call in this mode starts from, in ONE launch (four to five memsets took 8-25 us apiece in front of the
@@ -1422,7 +1423,8 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   using B = BlockGeo<W>;
   const size_t np = (size_t)1 << (2 * W);
   // lanes: option "em_overlap" (1 = one stream), as many as leave a lane at least eight PWMs (two by default: 16 PWMs x
-  // 10 iterations at W = 10 take 1.00 / 0.91 / 0.96 / 0.98 ms on 1 / 2 / 3 / 4 streams, 1000 PWMs 43 / 37.5 / 38.6 / 38.1 ms)
+  // 10 iterations at W = 10 take 0.92 / 0.83 / 0.86 / 0.84 ms on 1 / 2 / 3 / 4 streams, 1000 PWMs 38.5 / 33.8 / 34.5 / 39.5 ms;
+  // four lanes of four PWMs, two per half of the XCDs: 0.98 ms -- twelve launches per iteration are more than the host enqueues)
   int lanes = ctx->em_overlap < 1 ? 1 : ctx->em_overlap > MAX_EM_LANES ? MAX_EM_LANES : ctx->em_overlap;
   while (lanes > 1 && n_pwm < 8 * (int64_t)lanes) --lanes;
   const int64_t fit = std::max<int64_t>(1, (int64_t)(budget / lanes / (np * sizeof(float))));  // tables the budget holds per lane
