@@ -1424,7 +1424,8 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   const size_t np = (size_t)1 << (2 * W);
   // lanes: option "em_overlap" (1 = one stream), as many as leave a lane at least eight PWMs (two by default: 16 PWMs x
   // 10 iterations at W = 10 take 0.92 / 0.83 / 0.86 / 0.84 ms on 1 / 2 / 3 / 4 streams, 1000 PWMs 38.5 / 33.8 / 34.5 / 39.5 ms;
-  // four lanes of four PWMs, two per half of the XCDs: 0.98 ms -- twelve launches per iteration are more than the host enqueues)
+  // four lanes of four PWMs, two lanes per half of the XCDs: 0.98 ms, also inside bench.py's step, where the host is 3 ms ahead --
+  // twice the kernels, each with its own ramp and tail, is what costs, not the enqueueing)
   int lanes = ctx->em_overlap < 1 ? 1 : ctx->em_overlap > MAX_EM_LANES ? MAX_EM_LANES : ctx->em_overlap;
   while (lanes > 1 && n_pwm < 8 * (int64_t)lanes) --lanes;
   const int64_t fit = std::max<int64_t>(1, (int64_t)(budget / lanes / (np * sizeof(float))));  // tables the budget holds per lane
