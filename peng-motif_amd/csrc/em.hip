@@ -23,6 +23,35 @@
 
 namespace pengk {
 namespace {
+// Developer build -DPENGK_WG_TRACE (tools/em_wgtrace.py): every workgroup of the three kernels of the blocks-ahead EM leaves
+// {kernel, kind, workgroup, XCC, start, end} (s_memrealtime: the 100 MHz clock all XCCs share; s_memtime has a base of its own per XCC) in a device array -- where a kernel's microseconds go
+// when its instruction count explains a third of them.  Never part of the product build.
+#ifdef PENGK_WG_TRACE
+constexpr unsigned WG_TRACE_MAX = 1u << 20;
+__device__ unsigned long long g_wg_trace[3 * WG_TRACE_MAX];
+__device__ unsigned g_wg_trace_n;
+struct WgTrace {
+  unsigned long long t0;
+  unsigned kernel;
+  __device__ __forceinline__ WgTrace(unsigned k) : t0(__builtin_amdgcn_s_memrealtime()), kernel(k) {}
+  __device__ __forceinline__ void end(unsigned kind, unsigned wg) const {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20) & 0xFu;  // HW_REG_XCC_ID, bits 3:0
+    const unsigned i = atomicAdd(&g_wg_trace_n, 1u);
+    if (i < WG_TRACE_MAX) {
+      g_wg_trace[3 * i] = ((unsigned long long)kernel << 56) | ((unsigned long long)kind << 48) | ((unsigned long long)xcc << 40) | wg;
+      g_wg_trace[3 * i + 1] = t0;
+      g_wg_trace[3 * i + 2] = t1;
+    }
+  }
+};
+#define PENGK_WG_TRACE_BEGIN(k) const WgTrace wg_trace(k)
+#define PENGK_WG_TRACE_END(kind, wg) wg_trace.end(kind, wg)
+#else
+#define PENGK_WG_TRACE_BEGIN(k)
+#define PENGK_WG_TRACE_END(kind, wg)
+#endif
 
 // HIMAX = 4: 256 leaves per thread (fewest partial products; best when the grid is full anyway).
 // HIMAX = 3 / 2: 64 / 16 leaves per thread, 4x / 16x more workgroups -- for small PWM batches that would
@@ -914,6 +943,7 @@ __global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __res
                                                               float saturation, float* __restrict__ wbuf, uint32_t* __restrict__ bad,
                                                               float* __restrict__ sums, const uint32_t* __restrict__ bg_range) {
   using G = BlockGeo<W>;
+  PENGK_WG_TRACE_BEGIN(1);
   const uint32_t pw = blockIdx.y, sp = blockIdx.x;
   __shared__ float s_pwm[W * 4];
   __shared__ float part[4][28];
@@ -1025,6 +1055,7 @@ __global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __res
       o[(size_t)(4u * p + G::high_digit(p, sp)) * G::NBLK + G::high_block(p, sp, a)] = v;
     }
   }
+  PENGK_WG_TRACE_END(0, blockIdx.x + gridDim.x * blockIdx.y);
 }
 
 // The prefix of a cell's block sums -> block_binade of every block (cells of more than 1024 blocks; the shorter ones are
@@ -1130,6 +1161,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
   using G = BlockGeo<W>;
   // (consecutive workgroups go to consecutive XCDs: a PWM's spans, and behind them its chains, stay on one -- as in
   // em_fold_scan_kernel; 1000 PWMs x 10 iterations: 35.5 ms, with PWM = blockIdx.y 37.5)
+  PENGK_WG_TRACE_BEGIN(2);
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
   __shared__ __attribute__((aligned(16))) float span[16384];
   const uint32_t t = threadIdx.x, lane = t & 63u;
@@ -1170,6 +1202,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
       out.pad = 0u;
       rec[((size_t)pw * G::CELLS + cell) * G::NBLK] = out;
     }
+    PENGK_WG_TRACE_END(1, lin);
     return;
   }
   const uint32_t sl = lin - extra_wgs, slot = sl >> 3;
@@ -1198,12 +1231,18 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
   // (kept in a register, lane i = this wave's i-th block: with nothing in LDS beside the span a workgroup takes exactly
   // 64 KiB, and two of them fit a CU's 160 KiB beside a chain workgroup's 32 KiB of the other lane -- 1 % on every EM figure)
   uint32_t binades = seqsum::NO_BINADE;
+  if constexpr (G::PREDICT_IN_EVAL) {
+    // The block sums of SEVERAL of this wave's cells are asked for together, then reduced: one task after the other -- load,
+    // wait, reduce, next -- the five round trips stood in front of every span's evaluation (5.8 of a workgroup's 10.9 us,
+    // tools/em_wgtrace.py).  All tasks at once where a cell has up to 256 blocks, two at a time above that (16 loads each).
+    constexpr uint32_t LOADS = G::NBLK / 64u, GROUP = LOADS <= 4u ? TASKS : 2u;
 #pragma unroll 1
-  for (uint32_t i = 0; i < TASKS; ++i) {
-    const uint32_t task = wave + SPAN_EVAL_WAVES * i;
-    if (task < G::CELLS) {
-      const uint32_t cell = cell_of(task), b = block_of(task);
-      if constexpr (G::PREDICT_IN_EVAL) {
+    for (uint32_t i0 = 0; i0 < TASKS; i0 += GROUP) {
+      float part[GROUP], own[GROUP];
+#pragma unroll
+      for (uint32_t g = 0; g < GROUP; ++g) {
+        const uint32_t task = min(wave + SPAN_EVAL_WAVES * (i0 + g), G::CELLS - 1u);  // (a task past the last cell: looked at by nobody)
+        const uint32_t cell = cell_of(task), b = block_of(task);
         const float* cs = sums + ((size_t)pw * G::CELLS + cell) * G::NBLK;
         float acc = 0.0f;
 #pragma unroll
@@ -1211,12 +1250,27 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
           const float x = cs[c + lane];
           acc += c + lane < b ? x : 0.0f;
         }
+        part[g] = acc;
+        own[g] = cs[b];
+      }
+#pragma unroll
+      for (uint32_t g = 0; g < GROUP; ++g) {
+        const uint32_t i = i0 + g, task = wave + SPAN_EVAL_WAVES * i;
+        float acc = part[g];
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
-        const uint32_t e = block_binade((double)acc, (double)acc + (double)cs[b], skew, cell * G::NBLK + b);  // (the same in all lanes)
-        if (lane == i) binades = e;
-      } else {
-        const uint32_t e = cells[(size_t)cell * G::NBLK + b].e;
+        if (i < TASKS && task < G::CELLS) {
+          const uint32_t e = block_binade((double)acc, (double)acc + (double)own[g], skew, cell_of(task) * G::NBLK + block_of(task));  // (the same in all lanes)
+          if (lane == i) binades = e;
+        }
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (uint32_t i = 0; i < TASKS; ++i) {
+      const uint32_t task = wave + SPAN_EVAL_WAVES * i;
+      if (task < G::CELLS) {
+        const uint32_t e = cells[(size_t)cell_of(task) * G::NBLK + block_of(task)].e;
         if (lane == i) binades = e;
       }
     }
@@ -1231,6 +1285,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
     }
   }
   __syncthreads();
+  PENGK_WG_TRACE_END(2, lin);  // (the span is in LDS)
 #pragma unroll 1
   for (uint32_t task = wave, i = 0; task < G::CELLS; task += SPAN_EVAL_WAVES, ++i) {
     const uint32_t p = task >> 2, j = task & 3u;
@@ -1254,6 +1309,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
       *r = out;
     }
   }
+  PENGK_WG_TRACE_END(0, lin);
 }
 
 template <int W>
@@ -1263,6 +1319,7 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
                                                       float* __restrict__ pwms, float* __restrict__ change_out, float threshold,
                                                       int max_it, unsigned long long* __restrict__ counters) {
   using G = BlockGeo<W>;
+  PENGK_WG_TRACE_BEGIN(3);
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
   if (pw >= n_pwm) return;
@@ -1308,6 +1365,7 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
     arrived = __hip_atomic_fetch_add(&done[pw], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+  PENGK_WG_TRACE_END(wc.fetched > 255u ? 255u : wc.fetched, lin);  // (kind = blocks taken the long way)
   if (arrived != G::CELLS - 1u) return;
   // The one finalizing wave of a PWM: everything it reads below was written by other workgroups of THIS launch before
   // their fetch_add on done[pw] (the exchange on `partials` returned first).  The acquire fence makes that order explicit
@@ -1318,6 +1376,7 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
   asm volatile("" ::: "memory");
   if (lane == 0) done[pw] = 0u;
   finalize_pwm<W, 16>((int)pw, pwms, state, change_out, partials, threshold, max_it, bad, wbuf, G::NP, lds);
+  PENGK_WG_TRACE_END(254, lin);  // (the PWM's last chain, with the finalize step)
 }
 
 __global__ void em_init_kernel(int n, int W, float threshold, int max_it, int32_t* __restrict__ state,
@@ -1372,6 +1431,24 @@ int launch_geo(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, f
   }
   return PENGK_OK;
 }
+
+#ifdef PENGK_WG_TRACE
+}  // namespace
+}  // namespace pengk
+// copies up to `max` records (3 words each) to `out`, returns how many there were, and starts over
+extern "C" __attribute__((visibility("default"))) long long pengk_debug_wg_trace(unsigned long long* out, unsigned max) {
+  unsigned n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(pengk::g_wg_trace_n), sizeof n) != hipSuccess) return -1;
+  const unsigned m = n < max ? n : max;
+  if (m && hipMemcpyFromSymbol(out, HIP_SYMBOL(pengk::g_wg_trace), (size_t)m * 3 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const unsigned zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(pengk::g_wg_trace_n), &zero, sizeof zero) != hipSuccess) return -1;
+  return (long long)n;
+}
+namespace pengk {
+namespace {
+#endif
 
 #ifdef PENGK_SEQSUM_STATS
 }  // namespace
