@@ -137,6 +137,7 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_em_tables) (void)hipFree(ctx->d_em_tables);
   if (ctx->d_em_blocks) (void)hipFree(ctx->d_em_blocks);
   if (ctx->d_em_counters) (void)hipFree(ctx->d_em_counters);
+  if (ctx->d_em_look) (void)hipFree(ctx->d_em_look);
   for (int l = 0; l < 3; ++l) {
     if (ctx->em_streams[l]) (void)hipStreamDestroy(ctx->em_streams[l]);
     if (ctx->em_join[l]) (void)hipEventDestroy(ctx->em_join[l]);
@@ -177,9 +178,18 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     return PENGK_OK;
   }
   if (strcmp(name, "em_serial_scan") == 0) {
-    if (value < 0 || value > 2)
-      return fail(PENGK_ERR_ARG, "em_serial_scan must be 0 (dependent additions), 1 (scan) or 2 (scan, blocks evaluated ahead)");
+    if (value < 0 || value > 3)
+      return fail(PENGK_ERR_ARG, "em_serial_scan must be 0 (dependent additions), 1 (scan), 2 (scan, blocks evaluated ahead) or 3 (the same in two launches per iteration)");
     ctx->em_serial_scan = (int)value;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "em_block0") == 0) {
+    ctx->em_block0 = value != 0;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "em_test_lookback") == 0) {
+    if (value < 0 || value > 1000000) return fail(PENGK_ERR_ARG, "em_test_lookback must be 0 (off) or the n of 'every n-th workgroup'");
+    ctx->em_test_lookback = (int)value;
     return PENGK_OK;
   }
   if (strcmp(name, "em_test_skew") == 0) {

@@ -1379,6 +1379,598 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
   PENGK_WG_TRACE_END(254, lin);  // (the PWM's last chain, with the finalize step)
 }
 
+// ---- weights, block sums, estimates and block evaluation as ONE kernel (em_serial_scan = 3; W = 10, 12) -----------------
+// An iteration of the blocks-ahead scheme above was three dependent launches -- weights (table + block sums), block
+// evaluation (the table read back, span by span), chains -- with the finalize step at the end of the last one, behind an
+// arrival counter.  Here it is two:
+//   em_span_fused_kernel   a workgroup per span: the PREVIOUS iteration's finalize step at its head (every workgroup of a
+//                          PWM repeats the 4 W divisions from the cell sums the chains left -- no arrival protocol, no
+//                          launch), the span's weights computed into LDS (and stored once, for the chains' fetches),
+//                          the span's block sums published, the estimates of the sums in front of its blocks from a
+//                          LOOK-BACK over the earlier spans of the PWM, the blocks evaluated from LDS;
+//   em_chain_store_kernel  one wave per cell walks the records (seqsum::walk_chain) and stores the cell's sum.
+// The table is written once and read only where a chain takes a block the long way (W = 12: 64 MiB per PWM and iteration
+// instead of 64 written + 64 read).
+//
+// The look-back.  Span sp publishes A[sp][cell] = what its weights add to each of the 4 W cells, as 64-bit words {epoch of
+// this launch, float}: one relaxed device-scope store per cell, data and "ready" in one word, no fence.  A workgroup adds
+// up the words of the earlier spans of its chunk of 64 -- eight per wave, all requested at once -- and the chunk totals
+// T[c] of the earlier chunks, which the last span of every chunk publishes the same way.  It only ever waits for
+// workgroups with a SMALLER linear index, and the wait is BOUNDED: when the deadline (LOOKBACK_TICKS of the 100 MHz
+// clock) passes, the workgroup marks its blocks "no binade" and goes on -- the chain then folds them term by term, which
+// costs time and never the result (seqsum.h: exactness does not rest on the estimates).  So neither an unexpected
+// dispatch order nor a lost workgroup can hang the launch.  Test hook em_test_lookback = n: every n-th workgroup acts as
+// if its deadline had passed.
+struct FusedGeo {
+  static constexpr uint32_t THREADS = 512, WAVES = 8, CHUNK = 64;
+  static constexpr unsigned long long LOOKBACK_TICKS = 50000ull;  // 500 us
+};
+template <int W>
+struct LookGeo {
+  using G = BlockGeo<W>;
+  static constexpr uint32_t CHUNKS = (G::SPANS + FusedGeo::CHUNK - 1u) / FusedGeo::CHUNK;
+  static_assert(CHUNKS <= 64u, "two levels: the earlier spans of a chunk, the earlier chunks");
+  static constexpr size_t WORDS_PER_PWM = (size_t)(G::SPANS + CHUNKS) * G::CELLS;  // A[span][cell] | T[chunk][cell]
+};
+__device__ __forceinline__ unsigned long long look_word(uint32_t epoch, float v) {
+  uint32_t b = __float_as_uint(v);
+  if (b > 0x7F800000u) b = 0x7F800000u;  // (a NaN or a negative sum -- degenerate weights -- travels as +inf: no binade)
+  return ((unsigned long long)epoch << 32) | b;
+}
+__device__ __forceinline__ unsigned long long look_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// What F_j, the finalize step of iteration j, makes of a PWM: the reference's float32 epilogue -- normalise rows
+// (src/peng.cpp:129, src/iupac_pattern.cpp:291-303), change = sum |new - old| in p-major order (:132-137) -- from the cell
+// sums in s_new[0 .. 4 W) and the previous PWM in s_old[0 .. 4 W) (LDS; every thread of the workgroup calls it between
+// two barriers of its own).  The new PWM is left in s_new, the cells' |new - old| in s_old; returns `change` (the same
+// value in every thread: each adds up the 4 W differences itself, in p-major order, from 16-byte LDS reads).
+template <int W>
+__device__ __forceinline__ float finalize_rows(float* s_new, float* s_old, uint32_t t) {
+  typedef seqsum::f4 f4;
+  float mine = 0.0f, diff = 0.0f;
+  if (t < 4u * W) {
+    const f4 row = reinterpret_cast<const f4*>(s_new)[t >> 2];
+    float sum = 0.0f;
+    sum += row.x;
+    sum += row.y;
+    sum += row.z;
+    sum += row.w;
+    mine = s_new[t] / sum;
+    diff = fabsf(mine - s_old[t]);
+  }
+  __syncthreads();
+  if (t < 4u * W) {
+    s_new[t] = mine;
+    s_old[t] = diff;
+  }
+  __syncthreads();
+  float change = 0.0f;
+  f4 d[W];
+#pragma unroll
+  for (int p = 0; p < W; ++p) d[p] = reinterpret_cast<const f4*>(s_old)[p];
+#pragma unroll
+  for (int p = 0; p < W; ++p) {
+    change += d[p].x;
+    change += d[p].y;
+    change += d[p].z;
+    change += d[p].w;
+  }
+  return change;
+}
+
+// The pieces of the per-PWM state the two-launch scheme keeps beside the caller's arrays (all indexed by PWM):
+//   run[2][n]     run[j & 1] = "still running" behind F_j; launch k reads run[k & 1] (= behind F_(k-2)) and writes
+//                 run[(k - 1) & 1]; the chains of launch k read what it wrote.  Never read and written by one launch.
+//   pwm1[n][4 W]  PWM_j for odd j (even j: the caller's array): launch k reads PWM_(k-2), writes PWM_(k-1) to the other one.
+//   bad[2][n]     bad[k & 1] = "launch k met a weight the scan cannot take" (read by its chains); launch k clears the other.
+struct FusedState {
+  uint32_t* run;       // [2][n]
+  float* pwm0;         // the caller's PWMs (PWM_j, j even)
+  float* pwm1;         // scratch (j odd)
+  uint32_t* bad;       // [2][n]
+  const float* cellsum;  // [n][4 W]: what the chains of the previous launch left
+  int32_t* state;      // the caller's {iterations, running} pairs
+  float* change;       // the caller's `change`
+  uint32_t n;          // PWMs of this batch
+  uint32_t run_stride, bad_stride;  // words between the two copies of run[] / bad[]
+};
+
+// Common head of every workgroup of em_span_fused_kernel: F_(k-1) for PWM pw, or PWM_0 at k = 1.  Leaves the PWM the
+// weights are to be computed from in s_pwm and returns whether the PWM is still running.  `writer`: this workgroup
+// records the step (exactly one workgroup per PWM and launch).
+template <int W>
+__device__ __forceinline__ bool fused_head(const FusedState& fs, uint32_t pw, uint32_t k, float threshold, int max_it, bool writer,
+                                           float* s_pwm, float* s_old, uint32_t t) {
+  constexpr uint32_t CELLS = 4u * W;
+  const uint32_t was_running = fs.run[(size_t)(k & 1u) * fs.run_stride + pw];
+  const float* prev = (k >= 2u && (k & 1u)) ? fs.pwm1 : fs.pwm0;  // PWM_(k-2) (k = 1: PWM_0)
+  float old = 0.0f, sum = 0.0f;
+  if (t < CELLS) {
+    old = prev[(size_t)pw * CELLS + t];
+    if (k >= 2u) sum = fs.cellsum[(size_t)pw * CELLS + t];
+  }
+  if (!was_running) {  // (workgroup-uniform)
+    if (writer && t == 0) {
+      fs.run[(size_t)((k - 1u) & 1u) * fs.run_stride + pw] = 0u;
+      fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
+    }
+    return false;
+  }
+  if (k < 2u) {
+    if (t < CELLS) s_pwm[t] = old;
+    if (writer && t == 0) fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
+    __syncthreads();
+    return true;
+  }
+  if (t < CELLS) {
+    s_pwm[t] = sum;
+    s_old[t] = old;
+  }
+  __syncthreads();
+  const float change = finalize_rows<W>(s_pwm, s_old, t);
+  const int it = (int)k - 1;
+  const bool running = !(change <= threshold || it >= max_it);
+  if (writer) {
+    float* next = (k & 1u) ? fs.pwm0 : fs.pwm1;  // PWM_(k-1)
+    if (t < CELLS) next[(size_t)pw * CELLS + t] = s_pwm[t];
+    if (t == 0) {
+      fs.state[2 * pw] = it;
+      fs.state[2 * pw + 1] = running ? 1 : 0;
+      fs.change[pw] = change;
+      fs.run[(size_t)((k - 1u) & 1u) * fs.run_stride + pw] = running ? 1u : 0u;
+      fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
+    }
+  }
+  return running;
+}
+
+// One weight, the reference's operations (src/peng.cpp:124-125, 180-197): x = the pattern, pr over the PWM's columns in
+// position order.
+template <int W, bool LEAN>
+__device__ __forceinline__ float weight_of(const float* s_pwm, uint32_t x, uint32_t cnt, float b, float saturation) {
+  float pr = 1.0f;
+#pragma unroll
+  for (int p = 0; p < W; ++p) pr = pr * s_pwm[p * 4 + ((x >> (2 * p)) & 3u)];
+  const float odds = em_div<LEAN>(pr, b);
+  return em_div<LEAN>((float)cnt * saturation, 1 + em_div<LEAN>(saturation, odds));
+}
+
+template <int W>
+__global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void em_span_fused_kernel(FusedState fs, uint32_t k, float threshold, int max_it,
+                                                                          const uint32_t* __restrict__ counts,
+                                                                          const float* __restrict__ bg, float saturation,
+                                                                          float* __restrict__ wbuf, seqsum::BlockRecord* __restrict__ rec,
+                                                                          unsigned long long* __restrict__ look, uint32_t epoch,
+                                                                          const uint32_t* __restrict__ bg_range, uint32_t skew,
+                                                                          uint32_t test_lookback, uint32_t extra_wgs) {
+  using G = BlockGeo<W>;
+  using LG = LookGeo<W>;
+  constexpr uint32_t CELLS = G::CELLS, WAVES = FusedGeo::WAVES;
+  PENGK_WG_TRACE_BEGIN(2);
+  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
+  __shared__ __attribute__((aligned(16))) float span[16384];
+  __shared__ __attribute__((aligned(16))) float s_pwm[CELLS], s_old[CELLS];
+  __shared__ float s_part[WAVES][28];
+  __shared__ float s_cell[CELLS];        // what this span adds to each cell
+  __shared__ float s_look[2][WAVES][CELLS];  // the waves' shares of the look-back: [0] earlier spans of the chunk, [1] earlier chunks
+  __shared__ uint32_t s_ok[WAVES];
+  __shared__ uint32_t s_lean;
+  const uint32_t t = threadIdx.x, lane = t & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+  uint32_t* bad_now = fs.bad + (size_t)(k & 1u) * fs.bad_stride;
+  const uint32_t bg_lo = bg_range[0], bg_hi = bg_range[1];
+
+  if (lin < extra_wgs) {
+    // The workgroups IN FRONT of the spans': BLOCK 0 of every cell, whose start is known exactly (zero) and which is the
+    // dearest block of a chain -- the sum climbs through some twenty binades in it.  Four cells per workgroup, two waves
+    // each: the block's 4096 weights are computed here a second time (a sixth of the table's; nobody to wait for), row by
+    // row -- at step i lane l takes term 64 i + l, so that the loads of a step are as contiguous as the cell allows -- into
+    // the layout Row::read_staged reads; the even wave of the pair then folds the block from zero.
+    const uint32_t xslot = lin >> 3;
+    constexpr uint32_t XW = (CELLS + 3u) / 4u;  // workgroups per PWM
+    const uint32_t pw = (lin & 7u) + 8u * (xslot / XW), cell = 4u * (xslot % XW) + (wave >> 1);
+    if (pw >= fs.n) return;
+    if (!fused_head<W>(fs, pw, k, threshold, max_it, false, s_pwm, s_old, t)) return;
+    if (t == 0) s_lean = lean_ranges_ok<W>(s_pwm, bg_lo, bg_hi, saturation) ? 1u : 0u;
+    __syncthreads();
+    const bool lean = s_lean != 0u, live = cell < CELLS;
+    const uint32_t p = cell >> 2, a = cell & 3u;
+    float* buf = span + (wave >> 1) * seqsum::BLOCK;
+    uint32_t worst = 0u;
+    auto fill = [&](auto lean_tag) {
+      constexpr bool LEAN = decltype(lean_tag)::value;
+#pragma unroll 4
+      for (uint32_t i = 32u * (wave & 1u); i < 32u * (wave & 1u) + 32u; ++i) {
+        const uint32_t c = 64u * i + lane;  // term c of the cell: x = [c's digits p.. | a | c's digits 0..p-1]
+        const uint32_t x = ((c >> (2u * p)) << (2u * p + 2u)) | (a << (2u * p)) | (c & ((1u << (2u * p)) - 1u));
+        const float v = weight_of<W, LEAN>(s_pwm, x, counts[x], bg[x], saturation);
+        worst = max(worst, __float_as_uint(v));
+        buf[(16u * i + ((lane >> 2) ^ (i & 15u))) * 4u + (lane & 3u)] = v;  // (row i, Row::read_staged's layout)
+      }
+    };
+    if (live) {
+      if (lean) fill(std::true_type{});
+      else fill(std::false_type{});
+    }
+    if (worst > 0x7F7FFFFFu) bad_now[pw] = 1u;
+    __syncthreads();
+    if (!live || (wave & 1u)) return;
+    seqsum::Row mine;
+    mine.read_staged((const seqsum::lds_float*)buf, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    seqsum::Stats st;
+    // (a flagged PWM: its chains sum the table by the plain loop and look at no record; fold_block's loop ends whatever
+    // the terms are -- `first` grows every turn)
+    const float s0 = seqsum::fold_block(mine, lane, 0.0f, st);
+    if (lane == 0) {
+      seqsum::BlockRecord out;
+      out.e = seqsum::SUM_BEHIND;
+      out.d0 = s0;
+      out.d1 = 0.0f;
+      out.pad = 0u;
+      rec[((size_t)pw * CELLS + cell) * G::NBLK] = out;
+    }
+    PENGK_WG_TRACE_END(1, lin);
+    return;
+  }
+
+  const uint32_t sl = lin - extra_wgs, slot = sl >> 3;
+  const uint32_t pw = (sl & 7u) + 8u * (slot / G::SPANS), sp = slot % G::SPANS;
+  if (pw >= fs.n) return;
+  const uint32_t* cnt = counts + (size_t)sp * 16384u;
+  const float* bgs = bg + (size_t)sp * 16384u;
+  if (!fused_head<W>(fs, pw, k, threshold, max_it, sp == 0u, s_pwm, s_old, t)) return;
+  if (t == 0) s_lean = lean_ranges_ok<W>(s_pwm, bg_lo, bg_hi, saturation) ? 1u : 0u;  // (workgroup-uniform: one PWM, one table)
+  __syncthreads();
+  const bool lean = s_lean != 0u;
+  PENGK_WG_TRACE_END(4, lin);  // (the head is done)
+
+  // ---- the span's weights: thread = digits 0..3 of x (t & 255) and the upper half of digit 6 (t >> 8); 32 x per thread
+  // over digits 4, 5 and the lower half of digit 6.  The product over the PWM's columns in the reference's order.
+  unsigned long long* my_look = look + (size_t)pw * LG::WORDS_PER_PWM;
+  // (look-back, below: wave w adds the earlier spans j = w (mod 8) of its chunk and the earlier chunks c = w (mod 8); the
+  // words are ASKED FOR here, behind the weights and in front of the reductions and the barrier -- the earlier spans
+  // started earlier, most of their words are there by now, and the round trip is hidden)
+  const uint32_t chunk = sp / FusedGeo::CHUNK, c0 = chunk * FusedGeo::CHUNK, n0 = sp - c0;
+  constexpr uint32_t PER = FusedGeo::CHUNK / WAVES;              // spans per wave
+  constexpr uint32_t PERC = (LG::CHUNKS + WAVES - 1u) / WAVES;   // chunk totals per wave
+  const unsigned long long* src[PER + PERC];
+  unsigned long long v[PER + PERC];
+  bool need[PER + PERC];
+  {
+    float* out_t = wbuf + (size_t)pw * G::NP + (size_t)sp * 16384u + (t & 255u);
+    const uint32_t* cnt_t = cnt + (t & 255u);
+    const float* bg_t = bgs + (t & 255u);
+    const uint32_t tl = t & 255u, h = t >> 8, w3 = (t >> 6) & 3u;
+    float p3 = 1.0f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) p3 = p3 * s_pwm[p * 4 + ((tl >> (2 * p)) & 3u)];
+    float hi[W - 7];  // the span's own digits 7 .. W-1 (wave-uniform)
+#pragma unroll
+    for (int p = 7; p < W; ++p) hi[p - 7] = s_pwm[p * 4 + ((sp >> (2 * (p - 7))) & 3u)];
+    float f4_[4], f5_[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      f4_[a] = s_pwm[16 + a];
+      f5_[a] = s_pwm[20 + a];
+    }
+    float c4[4] = {0, 0, 0, 0}, c5[4] = {0, 0, 0, 0}, c6[2] = {0, 0};
+    uint32_t worst = 0u;  // the largest bit pattern among the weights: above +inf's = negative or NaN
+    // LDS: float xl of the span lies at 4 (R 16 + (k ^ g(R))) + (xl & 3), R = xl >> 6, k = (xl >> 2) & 15 (SpanLds).  With
+    // xl = tl + 256 (d4 + 4 d5 + 16 d6): R = w3 + 4 d4 + 16 d5 + 64 d6 and g(R) = w3 ^ C(d4, d5) ^ G6(d6), so the byte
+    // address is (a6 ^ 16 C(d4, d5)) + 256 (4 d4 + 16 d5) with a6 per thread and d6: one xor per x.
+    const uint32_t kslot = (tl >> 2) & 15u, comp = tl & 3u;
+    char* span_b = reinterpret_cast<char*>(span);
+    auto body = [&](auto lean_tag) {
+      constexpr bool LEAN = decltype(lean_tag)::value;
+#pragma unroll 1
+      for (uint32_t i6 = 0; i6 < 2u; ++i6) {  // (not unrolled: 16 x in flight per turn keep the kernel at 128 registers, two workgroups per CU)
+        const uint32_t d6 = 2u * h + i6;
+        const float f6 = s_pwm[24 + d6];
+        const uint32_t g6 = (((d6 & 1u) << 3) ^ ((d6 & 3u) << 2)) & 15u;
+        const uint32_t a6 = 256u * (w3 + 64u * d6) + 4u * comp + 16u * ((kslot ^ w3 ^ g6) & 15u);
+        float* out6 = out_t + 4096u * d6;
+        const uint32_t* cnt6 = cnt_t + 4096u * d6;
+        const float* bg6 = bg_t + 4096u * d6;
+        float s6 = 0.0f;
+#pragma unroll
+        for (uint32_t d5 = 0; d5 < 4u; ++d5) {
+          float s5 = 0.0f;
+#pragma unroll
+          for (uint32_t d4 = 0; d4 < 4u; ++d4) {
+            constexpr uint32_t dummy = 0u;
+            (void)dummy;
+            const uint32_t m2 = d4 + 4u * d5;
+            const uint32_t cc = ((d4 << 2) ^ (d4 >> 1) ^ (d5 << 1) ^ d5) & 15u;
+            float pr = ((p3 * f4_[d4]) * f5_[d5]) * f6;
+#pragma unroll
+            for (int p = 7; p < W; ++p) pr = pr * hi[p - 7];
+            const float odds = em_div<LEAN>(pr, bg6[256u * m2]);
+            const float v = em_div<LEAN>((float)cnt6[256u * m2] * saturation, 1 + em_div<LEAN>(saturation, odds));  // :124-125
+            out6[256u * m2] = v;
+            *reinterpret_cast<float*>(span_b + ((a6 ^ (16u * cc)) + 256u * (4u * d4 + 16u * d5))) = v;
+            worst = max(worst, __float_as_uint(v));
+            c4[d4] += v;
+            s5 += v;
+          }
+          c5[d5] += s5;
+          s6 += s5;
+        }
+        c6[0] += i6 ? 0.0f : s6;
+        c6[1] += i6 ? s6 : 0.0f;
+      }
+    };
+    if (lean) body(std::true_type{});
+    else body(std::false_type{});
+    if (worst > 0x7F7FFFFFu) bad_now[pw] = 1u;  // (this PWM's cells are summed by the chain kernel's plain loop)
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) {
+      const uint32_t j = wave + WAVES * i;
+      need[i] = j < n0 && lane < CELLS;
+      src[i] = my_look + (size_t)(c0 + (j < n0 ? j : 0u)) * CELLS + (lane < CELLS ? lane : 0u);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < PERC; ++i) {
+      const uint32_t c = wave + WAVES * i;
+      need[PER + i] = c < chunk && lane < CELLS;
+      src[PER + i] = my_look + (size_t)(G::SPANS + (c < chunk ? c : 0u)) * CELLS + (lane < CELLS ? lane : 0u);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < PER + PERC; ++i) v[i] = need[i] ? look_load(src[i]) : 0ull;
+    // per wave: whole-wave sums by digit 4, 5, 6; the total by digit 0, 1, 2 (lane bits 0-1, 2-3, 4-5); the total (digit 3)
+    const float tot = c6[0] + c6[1];
+    auto all = [](float v) {
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+      return v;
+    };
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float s4 = all(c4[a]), s5 = all(c5[a]);
+      if (lane == 0) {
+        s_part[wave][12 + a] = s4;
+        s_part[wave][16 + a] = s5;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float s6 = all(c6[i]);
+      if (lane == 0) s_part[wave][20 + i] = s6;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {  // digit d = lane bits 2 d, 2 d + 1: add over the other four bits
+      float v = tot;
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1)
+        if (m != (1 << (2 * d)) && m != (2 << (2 * d))) v += __shfl_xor(v, m, 64);
+      if ((lane & ~(3u << (2 * d))) == 0u) s_part[wave][4 * d + (lane >> (2 * d))] = v;
+    }
+    {
+      const float v = all(tot);
+      if (lane == 0) s_part[wave][24] = v;
+    }
+  }
+  PENGK_WG_TRACE_END(3, lin);  // (this thread's weights are done)
+  __syncthreads();  // the span and the waves' partial sums are in LDS
+
+  // ---- what the span adds to every cell; published for the later spans of the PWM
+  if (t < CELLS) {
+    const uint32_t p = t >> 2, a = t & 3u;
+    auto over_waves = [&](uint32_t at) {
+      float v = 0.0f;
+#pragma unroll
+      for (uint32_t w = 0; w < WAVES; ++w) v += s_part[w][at];
+      return v;
+    };
+    float v;
+    if (p <= 2u) v = over_waves(4u * p + a);
+    else if (p == 3u) v = s_part[a][24] + s_part[a + 4u][24];  // digit 3 = wave & 3
+    else if (p <= 5u) v = over_waves(4u * (p - 1u) + a);        // digits 4, 5 at 12, 16
+    else {
+      // digit 6 = 2 (wave >> 2) + i; for p >= 7 the span lies in ONE cell of the position, whole
+      const uint32_t w0 = 4u * (a >> 1), at = 20u + (a & 1u);
+      const float q = (s_part[w0][at] + s_part[w0 + 1u][at]) + (s_part[w0 + 2u][at] + s_part[w0 + 3u][at]);
+      if (p == 6u) v = q;
+      else v = a == G::high_digit(p, sp) ? over_waves(24u) : 0.0f;
+    }
+    s_cell[t] = v;
+    __hip_atomic_store(my_look + (size_t)sp * CELLS + t, look_word(epoch, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // ---- look-back: what is not there yet is asked for again until it is, or until the deadline
+  {
+    bool ok = true;
+    const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + FusedGeo::LOOKBACK_TICKS;
+    float acc = 0.0f, acc_spans = 0.0f;
+#pragma unroll
+    for (uint32_t i = 0; i < PER + PERC; ++i) {
+      if (i == PER) {
+        acc_spans = acc;
+        acc = 0.0f;
+      }
+      // (the wave polls together: it leaves the loop when no lane waits any more, or at the deadline)
+      while (__builtin_amdgcn_ballot_w64(need[i] && (uint32_t)(v[i] >> 32) != epoch) != 0ull) {
+        if (__builtin_amdgcn_s_memrealtime() > deadline) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if (need[i] && (uint32_t)(v[i] >> 32) != epoch) v[i] = look_load(src[i]);
+      }
+      if (need[i] && (uint32_t)(v[i] >> 32) == epoch) acc += __uint_as_float((uint32_t)v[i]);
+    }
+    ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+    if (lane < CELLS) {
+      s_look[0][wave][lane] = acc_spans;
+      s_look[1][wave][lane] = acc;
+    }
+    if (lane == 0) s_ok[wave] = ok ? 1u : 0u;
+  }
+  __syncthreads();
+  bool est_ok = true;
+#pragma unroll
+  for (uint32_t w = 0; w < WAVES; ++w) est_ok &= s_ok[w] != 0u;
+  // the last span of a chunk publishes the chunk's total (earlier spans of the chunk + its own)
+  if (est_ok && (sp % FusedGeo::CHUNK) == FusedGeo::CHUNK - 1u && t < CELLS) {
+    float tot = s_cell[t];
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; ++w) tot += s_look[0][w][t];
+    __hip_atomic_store(my_look + (size_t)(G::SPANS + sp / FusedGeo::CHUNK) * CELLS + t, look_word(epoch, tot), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // (test hook: every n-th workgroup acts as if its deadline had passed -- after it has done its duty to the later chunks)
+  if (test_lookback != 0u && (lin * 2654435761u >> 20) % test_lookback == 0u) est_ok = false;
+  PENGK_WG_TRACE_END(2, lin);  // (the span is in LDS, the estimates are known)
+
+  // ---- the blocks of the span: task (p, j) -> its cell and block, as in em_span_eval_kernel
+  seqsum::BlockRecord* cells = rec + (size_t)pw * CELLS * G::NBLK;
+  auto cell_of = [&](uint32_t task) { return (task >> 2) <= 6u ? task : 4u * (task >> 2) + G::high_digit(task >> 2, sp); };
+  auto block_of = [&](uint32_t task) { return (task >> 2) <= 6u ? sp : G::high_block(task >> 2, sp, task & 3u); };
+#pragma unroll 1
+  for (uint32_t task = wave; task < CELLS; task += WAVES) {
+    const uint32_t p = task >> 2, j = task & 3u;
+    const uint32_t cell = cell_of(task), b = block_of(task);
+    if (b == 0u && extra_wgs != 0u) continue;  // (folded from zero by the workgroups in front of the spans')
+    seqsum::BlockRecord* r = cells + (size_t)cell * G::NBLK + b;
+    uint32_t e = seqsum::NO_BINADE;
+    if (est_ok) {
+      float before = 0.0f;
+#pragma unroll
+      for (uint32_t w = 0; w < WAVES; ++w) before += s_look[0][w][cell] + s_look[1][w][cell];
+      float own = s_cell[cell];
+      if (p >= 7u) {  // quarter j of the span: the quarters in front of it belong to the same cell
+        for (uint32_t q = 0; q < j; ++q) before += s_cell[24u + q];
+        own = s_cell[24u + j];
+      }
+      e = block_binade((double)before, (double)before + (double)own, skew, cell * G::NBLK + b);
+    }
+    if (e == seqsum::NO_BINADE) {
+      if (lane == 0) r->e = seqsum::NO_BINADE;
+      continue;
+    }
+    seqsum::Row mine;
+    span_row<W>(span, p, j, lane, mine);
+    float d0, d1;
+    const bool ok = seqsum::block_increments(mine, lane, seqsum::bases_of_binade(e), d0, d1);
+    if (lane == 0) {
+      seqsum::BlockRecord out;
+      out.e = ok ? e : seqsum::NO_BINADE;
+      out.d0 = d0;
+      out.d1 = d1;
+      out.pad = 0u;
+      *r = out;
+    }
+  }
+  PENGK_WG_TRACE_END(0, lin);
+}
+
+// The chains of a launch of em_span_fused_kernel: one wave per cell; the cell's sum is stored for the next launch's head
+// (or em_fused_finish_kernel) -- a plain store, the kernel boundary orders it.
+template <int W>
+__global__ __launch_bounds__(64) void em_chain_store_kernel(const uint32_t* __restrict__ run, const uint32_t* __restrict__ bad,
+                                                            const float* __restrict__ wbuf, const seqsum::BlockRecord* __restrict__ rec,
+                                                            float* __restrict__ cellsum, uint32_t n_pwm,
+                                                            unsigned long long* __restrict__ counters) {
+  using G = BlockGeo<W>;
+  PENGK_WG_TRACE_BEGIN(3);
+  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+  const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
+  if (pw >= n_pwm) return;
+  __shared__ __attribute__((aligned(16))) float lds[seqsum::WALK_LDS_FLOATS];
+  seqsum::WalkCounts wc;
+  const uint32_t lane = threadIdx.x;
+  const seqsum::BlockRecord* r = rec + ((size_t)pw * G::CELLS + cell) * G::NBLK;
+  // (the PWM's two flags and the chain's first 64 records are asked for together: one memory round trip at the head of
+  // every chain -- the kernel ends with its longest one)
+  uint32_t running = run[pw];
+  uint32_t flagged = bad[pw];
+  uint4 first = reinterpret_cast<const uint4*>(r)[lane];
+  asm volatile("" : "+s"(running), "+s"(flagged), "+v"(first.x), "+v"(first.y), "+v"(first.z), "+v"(first.w));
+  if (running == 0u) return;
+  float s = 0.0f;
+  const float* w = wbuf + (size_t)pw * G::NP;
+  if (flagged) {
+    // a PWM with a negative or non-finite weight (degenerate inputs only): the plain loop, the reference's own additions
+    const uint32_t p = cell >> 2, a = cell & 3u;
+    for (uint32_t c = 0; c < (1u << (2 * W - 2)); ++c)
+      s += w[((c >> (2u * p)) << (2u * p + 2u)) | (a << (2u * p)) | (c & ((1u << (2u * p)) - 1u))];
+  } else if ((cell >> 2) == 0u) {
+    EmTerms0<W> src0{w, cell & 3u};
+    src0.bind_stage(lane);
+    s = seqsum::walk_chain(src0, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
+  } else {
+    EmTerms<W> src{w, cell >> 2, cell & 3u};
+    src.bind_stage(lane);
+    s = seqsum::walk_chain(src, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
+  }
+  if (lane == 0) {
+    cellsum[(size_t)pw * G::CELLS + cell] = s;
+    if (wc.fetched) __hip_atomic_fetch_add(counters + 0, (unsigned long long)wc.fetched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.mispredicted) __hip_atomic_fetch_add(counters + 1, (unsigned long long)wc.mispredicted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.restaged) __hip_atomic_fetch_add(counters + 2, (unsigned long long)wc.restaged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.restaged_waits) __hip_atomic_fetch_add(counters + 3, (unsigned long long)wc.restaged_waits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  PENGK_WG_TRACE_END(wc.fetched > 255u ? 255u : wc.fetched, lin);
+}
+
+// Once per call and batch, behind the last launch's chains: F_K for the PWMs that are still running (K = launches = the
+// iteration limit: they stop here), and every PWM's final matrix into the caller's array (PWM_j lives there for even j).
+template <int W>
+__global__ __launch_bounds__(64) void em_fused_finish_kernel(FusedState fs, uint32_t K, float threshold, int max_it) {
+  constexpr uint32_t CELLS = 4u * W;
+  const uint32_t pw = blockIdx.x, t = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_pwm[CELLS], s_old[CELLS];
+  // run[(K-1) & 1] = running behind F_(K-1) -- what the last launch (k = K) wrote, or the initial flag at K = 1
+  const uint32_t running = fs.run[(size_t)((K - 1u) & 1u) * fs.run_stride + pw];
+  if (running) {
+    const float* prev = ((K - 1u) & 1u) ? fs.pwm1 : fs.pwm0;  // PWM_(K-1)
+    if (t < CELLS) {
+      s_old[t] = prev[(size_t)pw * CELLS + t];
+      s_pwm[t] = fs.cellsum[(size_t)pw * CELLS + t];
+    }
+    __syncthreads();
+    const float change = finalize_rows<W>(s_pwm, s_old, t);
+    if (t < CELLS) fs.pwm0[(size_t)pw * CELLS + t] = s_pwm[t];
+    if (t == 0) {
+      fs.state[2 * pw] = (int)K;
+      fs.state[2 * pw + 1] = !(change <= threshold || (int)K >= max_it);
+      fs.change[pw] = change;
+    }
+  } else {
+    const int it = fs.state[2 * pw];  // the PWM stopped behind F_it: PWM_it
+    if ((it & 1) && t < CELLS) fs.pwm0[(size_t)pw * CELLS + t] = fs.pwm1[(size_t)pw * CELLS + t];
+  }
+  if (t == 0) {
+    fs.bad[pw] = 0u;
+    fs.bad[(size_t)fs.bad_stride + pw] = 0u;
+  }
+}
+
+// What a call in this mode starts from: the caller's state as em_init_kernel leaves it, both copies of the "running"
+// flag, the "bad weight" flags, the chains' counters, the background's range for em_bg_range_kernel's min / max.
+__global__ __launch_bounds__(256) void em_fused_setup_kernel(uint32_t n, int W, float threshold, int max_it, int32_t* __restrict__ state,
+                                                             float* __restrict__ change, uint32_t* __restrict__ run,
+                                                             unsigned long long* __restrict__ counters, uint32_t* __restrict__ bg_range,
+                                                             uint32_t lean, uint32_t* __restrict__ bad, uint32_t bad_words) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < 4u) counters[i] = 0ull;
+  if (i == 0) {
+    bg_range[0] = lean ? 0xFFFFFFFFu : 0u;
+    bg_range[1] = lean ? 0u : 0xFFFFFFFFu;
+  }
+  for (uint32_t j = i; j < bad_words; j += gridDim.x * 256u) bad[j] = 0u;
+  if (i >= n) return;
+  const float c0 = (float)W;  // `float change = pattern_length` (src/peng.cpp:101)
+  const uint32_t r = !(c0 <= threshold || 0 >= max_it);
+  state[2 * i] = 0;
+  state[2 * i + 1] = (int32_t)r;
+  change[i] = c0;
+  run[i] = r;
+  run[n + i] = r;
+}
+
 __global__ void em_init_kernel(int n, int W, float threshold, int max_it, int32_t* __restrict__ state,
                                float* __restrict__ change) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1601,6 +2193,139 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   return rc_launch ? rc_launch : rc_join;
 }
 
+// The serial mode as two launches per iteration (em_serial_scan = 3; W = 10, 12): em_span_fused_kernel + em_chain_store_kernel
+// per batch of PWMs, batches taking turns on the lanes as in launch_serial_ahead, one em_fused_finish_kernel per batch.
+template <int W>
+int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
+                        const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change, size_t budget) {
+  using B = BlockGeo<W>;
+  using LG = LookGeo<W>;
+  const size_t np = (size_t)1 << (2 * W);
+  int lanes = ctx->em_overlap < 1 ? 1 : ctx->em_overlap > MAX_EM_LANES ? MAX_EM_LANES : ctx->em_overlap;
+  while (lanes > 1 && n_pwm < 8 * (int64_t)lanes) --lanes;
+  const int64_t fit = std::max<int64_t>(1, (int64_t)(budget / lanes / (np * sizeof(float))));  // tables the budget holds per lane
+  int64_t batch = fit;
+  if (batch * lanes > n_pwm) {
+    batch = lanes > 1 ? ((n_pwm + lanes - 1) / lanes + 7) / 8 * 8 : n_pwm;
+    if (batch > fit) batch = fit >= 8 ? fit / 8 * 8 : fit;
+  }
+  if (batch > 16384) batch = 16384;  // (grid size; far beyond any budget)
+  // per lane: tables | records | look-back words | cell sums, "bad weight" flags.  Per call: run[2][n] | PWM_odd[n][4 W]
+  const size_t tables_b = (size_t)batch * np * sizeof(float);
+  const size_t rec_b = ((size_t)batch * B::CELLS * B::NBLK * sizeof(seqsum::BlockRecord) + 255) / 256 * 256;
+  const size_t look_b = ((size_t)batch * LG::WORDS_PER_PWM * sizeof(unsigned long long) + 255) / 256 * 256;
+  const size_t flags_at = ((size_t)batch * B::CELLS * sizeof(float) + 255) / 256 * 256;
+  const size_t small_b = (flags_at + (size_t)2 * batch * sizeof(uint32_t) + 255) / 256 * 256;
+  const size_t run_at = lanes * small_b;
+  const size_t pwm1_at = (run_at + (size_t)2 * n_pwm * sizeof(uint32_t) + 255) / 256 * 256;
+  int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, lanes * tables_b);
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, pwm1_at + (size_t)n_pwm * B::CELLS * sizeof(float));
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes, lanes * rec_b);
+  if (rc) return rc;
+  {
+    // the look-back words carry the epoch of the launch that wrote them: a fresh buffer starts from zero (no launch has
+    // epoch 0), and so does a counter that has gone round
+    const size_t had = ctx->em_look_bytes;
+    rc = ensure_scratch(ctx, &ctx->d_em_look, &ctx->em_look_bytes, lanes * look_b);
+    if (rc) return rc;
+    if (ctx->em_look_bytes != had || ctx->em_epoch >= 0xFFFF0000u) {
+      PENGK_HIP(hipStreamSynchronize(ctx->stream));
+      for (int l = 0; l < MAX_EM_LANES - 1; ++l)
+        if (ctx->em_streams[l]) PENGK_HIP(hipStreamSynchronize(ctx->em_streams[l]));
+      PENGK_HIP(hipMemsetAsync(ctx->d_em_look, 0, ctx->em_look_bytes, ctx->stream));
+      ctx->em_epoch = 0;
+    }
+  }
+  if (!ctx->d_em_counters) PENGK_HIP(hipMalloc((void**)&ctx->d_em_counters, (EM_COUNTERS + 1) * sizeof(unsigned long long)));
+  uint32_t* bg_range = reinterpret_cast<uint32_t*>(ctx->d_em_counters + EM_COUNTERS);
+  char* small = reinterpret_cast<char*>(ctx->d_em_partials);
+  uint32_t* run = reinterpret_cast<uint32_t*>(small + run_at);
+  float* pwm1 = reinterpret_cast<float*>(small + pwm1_at);
+  // (the lanes' flag words lie small_b apart: the setup kernel clears everything from the first lane's flags to the last lane's)
+  {
+    const uint32_t words = (uint32_t)((run_at - flags_at) / sizeof(uint32_t));
+    hipLaunchKernelGGL(em_fused_setup_kernel, dim3((unsigned)((std::max<int64_t>(n_pwm, 1024) + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (uint32_t)n_pwm, W, threshold, max_it, d_state, d_change, run, ctx->d_em_counters, bg_range,
+                       ctx->em_lean_div ? 1u : 0u, reinterpret_cast<uint32_t*>(small + flags_at), words);
+    if (ctx->em_lean_div)
+      hipLaunchKernelGGL(em_bg_range_kernel, dim3(32), dim3(1024), 0, ctx->stream, d_bg, (uint32_t)np, bg_range);  // (np = 4^W: a multiple of 4)
+    PENGK_HIP(hipGetLastError());
+  }
+  if (max_it <= 0) return PENGK_OK;
+  hipStream_t streams[MAX_EM_LANES];
+  streams[0] = ctx->stream;
+  for (int l = 1; l < lanes; ++l) {
+    if (!ctx->em_streams[l - 1]) PENGK_HIP(hipStreamCreateWithFlags(&ctx->em_streams[l - 1], hipStreamNonBlocking));
+    if (!ctx->em_join[l - 1]) PENGK_HIP(hipEventCreateWithFlags(&ctx->em_join[l - 1], hipEventDisableTiming));
+    streams[l] = ctx->em_streams[l - 1];
+  }
+  if (lanes > 1 && !ctx->em_fork) PENGK_HIP(hipEventCreateWithFlags(&ctx->em_fork, hipEventDisableTiming));
+  if (lanes > 1) {  // (everything enqueued so far -- the tables' producers, the setup -- comes first on all of them)
+    PENGK_HIP(hipEventRecord(ctx->em_fork, ctx->stream));
+    for (int l = 1; l < lanes; ++l) PENGK_HIP(hipStreamWaitEvent(streams[l], ctx->em_fork, 0));
+  }
+  // Once the lanes are forked they are ALWAYS joined, also when a launch fails half way (launch_serial_ahead).
+  const int rc_launch = [&]() -> int {
+    for (int64_t round0 = 0; round0 < n_pwm; round0 += batch * lanes) {
+      for (int it = 1; it <= max_it + 1; ++it) {  // (turn max_it + 1: the batches' finish kernels)
+        for (int l = 0; l < lanes; ++l) {
+          const int64_t first = round0 + (int64_t)l * batch;
+          if (first >= n_pwm) break;
+          const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
+          hipStream_t st = streams[l];
+          float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_tables) + l * tables_b);
+          seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * rec_b);
+          unsigned long long* look = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->d_em_look) + l * look_b);
+          float* cellsum = reinterpret_cast<float*>(small + l * small_b);
+          uint32_t* bad = reinterpret_cast<uint32_t*>(small + l * small_b + flags_at);
+          FusedState fs;
+          fs.run = run + first;
+          fs.pwm0 = d_pwms + (size_t)first * W * 4;
+          fs.pwm1 = pwm1 + (size_t)first * W * 4;
+          fs.bad = bad;
+          fs.cellsum = cellsum;
+          fs.state = d_state + 2 * first;
+          fs.change = d_change + first;
+          fs.n = (uint32_t)nb;
+          fs.run_stride = (uint32_t)n_pwm;
+          fs.bad_stride = (uint32_t)batch;
+          if (it > max_it) {
+            hipLaunchKernelGGL((em_fused_finish_kernel<W>), dim3((unsigned)nb), dim3(64), 0, st, fs, (uint32_t)max_it, threshold, max_it);
+            continue;
+          }
+          const uint32_t k = (uint32_t)it;
+          const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
+          // block 0 of every cell: by workgroups in front of the spans' (option em_block0 = 1), or left to its chain
+          const uint64_t extra_wgs = ctx->em_block0 ? (uint64_t)groups * ((B::CELLS + 3) / 4) : 0;
+          const uint64_t wgs = extra_wgs + (uint64_t)groups * B::SPANS;
+          const unsigned gx = 1024u;
+          const uint32_t epoch = ++ctx->em_epoch;
+          hipLaunchKernelGGL((em_span_fused_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(FusedGeo::THREADS), 0, st, fs, k,
+                             threshold, max_it, d_counts, d_bg, saturation, tables, rec, look, epoch, (const uint32_t*)bg_range,
+                             (uint32_t)ctx->em_test_skew, (uint32_t)ctx->em_test_lookback, (uint32_t)extra_wgs);
+          hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st,
+                             (const uint32_t*)(run + (size_t)((k - 1u) & 1u) * n_pwm + first), (const uint32_t*)(bad + (size_t)(k & 1u) * batch),
+                             (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters);
+        }
+      }
+      PENGK_HIP(hipGetLastError());
+    }
+    return PENGK_OK;
+  }();
+  int rc_join = PENGK_OK;
+  for (int l = 1; l < lanes; ++l) {
+    hipError_t e = hipEventRecord(ctx->em_join[l - 1], streams[l]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->em_join[l - 1], 0);
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(streams[l]);  // the join could not be enqueued: wait here instead
+      if (!rc_join) rc_join = hip_fail(e, "joining the EM's streams");
+    }
+  }
+  return rc_launch ? rc_launch : rc_join;
+}
+
 #ifndef PENGK_EM_BUDGET_GIB
 #define PENGK_EM_BUDGET_GIB 24
 #endif
@@ -1638,7 +2363,11 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   constexpr bool COPY0 = SCAN && ScanCopy0<W>::value;
   // blocks evaluated ahead of the chain (W >= 10): span-major weights with block sums, no second copy of the table
   if constexpr (SCAN && W >= 10) {
-    if (scan && ctx->em_serial_scan == 2)
+    if constexpr (W <= 12) {  // (W = 14: 16384 spans per PWM would take a third look-back level; it keeps the three launches)
+      if (scan && ctx->em_serial_scan == 3)
+        return launch_serial_fused<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change, budget);
+    }
+    if (scan && ctx->em_serial_scan >= 2)
       return launch_serial_ahead<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change, budget);
   }
   const size_t pwm_stride = (scan && COPY0) ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)

@@ -28,6 +28,11 @@ struct pengk_ctx {
   size_t em_tables_bytes = 0;
   void* d_em_blocks = nullptr;   // K5 serial mode, blocks ahead of their chain: block sums | block records (em.hip)
   size_t em_blocks_bytes = 0;
+  void* d_em_look = nullptr;     // K5 serial mode, two launches per iteration: the look-back words of the spans (em.hip)
+  size_t em_look_bytes = 0;
+  uint32_t em_epoch = 0;         // ... and the epoch of the last launch that wrote them
+  int em_block0 = 0;             // K5 serial mode, two launches: block 0 of every cell folded 1 = by extra workgroups of the span kernel, 0 = by its chain
+  int em_test_lookback = 0;      // test hook: every n-th workgroup of em_span_fused_kernel acts as if its look-back had timed out
   unsigned long long* d_em_counters = nullptr;  // K5 serial mode: what the chains of the last pengk_em call met (seqsum::WalkCounts)
   hipStream_t em_streams[3] = {nullptr, nullptr, nullptr};  // K5 serial mode: the streams beside `stream` that batches of PWMs take turns on
   hipEvent_t em_fork = nullptr, em_join[3] = {nullptr, nullptr, nullptr};
@@ -47,8 +52,9 @@ struct pengk_ctx {
   uint64_t em_table_budget_mb = 0; // K5 serial mode: MiB of weight tables per batch of PWMs (0 = automatic)
   int em_test_skew = 0;         // test hook: every n-th block of the serial EM gets a wrong binade estimate (em.hip, block_binade)
   int em_overlap = 2;           // K5 serial mode, em_serial_scan = 2: streams that batches of PWMs take turns on (1 .. MAX_EM_LANES)
-  int em_serial_scan = 2;       // K5 serial mode: cells summed by 2 = the scan of seqsum.h with its blocks evaluated ahead of
-                                // the chain (W >= 10; else as 1), 1 = the scan, block after block, 0 = dependent additions
+  int em_serial_scan = 2;       // K5 serial mode: cells summed by 3 = the scan of seqsum.h with its blocks evaluated ahead of the
+                                // chain, two launches per iteration (W = 10, 12; else as 2), 2 = the same as three launches
+                                // (W >= 10; else as 1), 1 = the scan, block after block, 0 = dependent additions
   int em_lean_div = 1;          // K5 serial mode: the weights' divisions without range scaling where a PWM's operand ranges allow (em.hip, lean_div)
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--iter", type=int, default=3)
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--nseq", type=int, default=2_000_000)
+    ap.add_argument("--scan", type=int, default=3)
     a = ap.parse_args()
     W, NP = a.W, 4 ** a.W
     ctx = pk.Context(0)
@@ -52,6 +53,7 @@ def main():
     change = pk.DeviceArray.from_host(ctx, np.zeros(a.pwms, np.float32))
     ctx.set_option("em_fast", 2)
     ctx.set_option("em_overlap", a.streams)
+    ctx.set_option("em_serial_scan", a.scan)
     t0, t1 = ctx.timer(), ctx.timer()
     MAX = 1 << 20
     buf = np.zeros(3 * MAX, np.uint64)
@@ -76,7 +78,7 @@ def main():
     print("W=%d, %d PWMs x %d iterations on %d stream(s): %.1f us by the events, %d records, one tick ~ %.5f us" % (W, a.pwms, a.iters, a.streams, ms * 1e3, n, tick_us))
     T0 = int(s.min())
     for k in (1, 2, 3):
-        m = (kern == k) & ~((k == 2) & (kind == 2))
+        m = (kern == k) & ~((k == 2) & ((kind == 2) | (kind == 3) | (kind == 4)))
         if not m.any():
             continue
         # the launches of this kernel: its workgroups' starts, sorted, split where nothing starts for a while
@@ -102,10 +104,11 @@ def main():
             ex = kk[lo:hi] == 1
             if ex.any():
                 print("    block-0 workgroups: %d, run %.1f us on average (longest %.1f), the last ends at %.1f us" % (ex.sum(), dur[ex].mean(), dur[ex].max(), ends[ex].max()))
-            m2 = (kern == 2) & (kind == 2) & (s >= s0) & (s <= ee[lo:hi].max())
-            if m2.any():
-                ld = (e[m2] - s[m2]) * tick_us
-                print("    a span is in LDS %.1f us after its workgroup started (median %.1f, longest %.1f)" % (ld.mean(), np.median(ld), ld.max()))
+            for kd, what in ((4, "the head (previous iteration's finalize step) is done"), (3, "thread 0's weights are done"), (2, "a span is in LDS (and its estimates known)")):
+                m2 = (kern == 2) & (kind == kd) & (s >= s0) & (s <= ee[lo:hi].max())
+                if m2.any():
+                    ld = (e[m2] - s[m2]) * tick_us
+                    print("    %s %.1f us after its workgroup started (median %.1f, longest %.1f)" % (what, ld.mean(), np.median(ld), ld.max()))
         if k == 3:
             f = kk[lo:hi]
             nf = f[f < 254]
