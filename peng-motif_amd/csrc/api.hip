@@ -138,11 +138,14 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_em_blocks) (void)hipFree(ctx->d_em_blocks);
   if (ctx->d_em_counters) (void)hipFree(ctx->d_em_counters);
   if (ctx->d_em_look) (void)hipFree(ctx->d_em_look);
+  if (ctx->d_em_rows) (void)hipFree(ctx->d_em_rows);
   for (int l = 0; l < 3; ++l) {
     if (ctx->em_streams[l]) (void)hipStreamDestroy(ctx->em_streams[l]);
     if (ctx->em_join[l]) (void)hipEventDestroy(ctx->em_join[l]);
   }
   if (ctx->em_fork) (void)hipEventDestroy(ctx->em_fork);
+  for (int l = 0; l < 3; ++l)
+    if (ctx->em_step[l]) (void)hipEventDestroy(ctx->em_step[l]);
   if (ctx->d_misc) (void)hipFree(ctx->d_misc);
   if (ctx->d_keys) (void)hipFree(ctx->d_keys);
   if (ctx->d_iupac_big) (void)hipFree(ctx->d_iupac_big);
@@ -178,9 +181,17 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     return PENGK_OK;
   }
   if (strcmp(name, "em_serial_scan") == 0) {
-    if (value < 0 || value > 3)
-      return fail(PENGK_ERR_ARG, "em_serial_scan must be 0 (dependent additions), 1 (scan), 2 (scan, blocks evaluated ahead) or 3 (the same in two launches per iteration)");
+    if (value < 0 || value > 4)
+      return fail(PENGK_ERR_ARG, "em_serial_scan must be 0 (dependent additions), 1 (scan), 2 (scan, blocks evaluated ahead), 3 (the same in two launches per iteration) or 4 (in three, the finalize step at the head of the weights kernel)");
     ctx->em_serial_scan = (int)value;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "em_stagger") == 0) {
+    ctx->em_stagger = value != 0;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "em_rows") == 0) {
+    ctx->em_rows = value != 0;
     return PENGK_OK;
   }
   if (strcmp(name, "em_block0") == 0) {
@@ -245,8 +256,9 @@ int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value) {
   }
   // K5 serial mode, blocks ahead of their chain: what the chains of the LAST pengk_em / pengk_em_device call met, summed
   // over all cells, PWMs and iterations (seqsum::WalkCounts; 0 for every other EM mode).  Synchronises with the stream.
-  static const char* const em_names[4] = {"em_fetched_blocks", "em_mispredicted_blocks", "em_restaged_blocks", "em_restaged_waits"};
-  for (int i = 0; i < 4; ++i)
+  static const char* const em_names[6] = {"em_fetched_blocks", "em_mispredicted_blocks", "em_restaged_blocks", "em_restaged_waits",
+                                          "em_row_blocks", "em_row_failed"};
+  for (int i = 0; i < 6; ++i)
     if (strcmp(name, em_names[i]) == 0) {
       unsigned long long v = 0;
       if (ctx->d_em_counters) {

@@ -932,34 +932,148 @@ __global__ __launch_bounds__(256) void em_div_check_kernel(unsigned long long se
   atomicAdd(out + 2, zero);
 }
 
+// What F_j, the finalize step of iteration j, makes of a PWM: the reference's float32 epilogue -- normalise rows
+// (src/peng.cpp:129, src/iupac_pattern.cpp:291-303), change = sum |new - old| in p-major order (:132-137) -- from the cell
+// sums in s_new[0 .. 4 W) and the previous PWM in s_old[0 .. 4 W) (LDS; every thread of the workgroup calls it between
+// two barriers of its own).  The new PWM is left in s_new, the cells' |new - old| in s_old; returns `change` (the same
+// value in every thread: each adds up the 4 W differences itself, in p-major order, from 16-byte LDS reads).
+template <int W>
+__device__ __forceinline__ float finalize_rows(float* s_new, float* s_old, uint32_t t) {
+  typedef seqsum::f4 f4;
+  float mine = 0.0f, diff = 0.0f;
+  if (t < 4u * W) {
+    const f4 row = reinterpret_cast<const f4*>(s_new)[t >> 2];
+    float sum = 0.0f;
+    sum += row.x;
+    sum += row.y;
+    sum += row.z;
+    sum += row.w;
+    mine = s_new[t] / sum;
+    diff = fabsf(mine - s_old[t]);
+  }
+  __syncthreads();
+  if (t < 4u * W) {
+    s_new[t] = mine;
+    s_old[t] = diff;
+  }
+  __syncthreads();
+  float change = 0.0f;
+  f4 d[W];
+#pragma unroll
+  for (int p = 0; p < W; ++p) d[p] = reinterpret_cast<const f4*>(s_old)[p];
+#pragma unroll
+  for (int p = 0; p < W; ++p) {
+    change += d[p].x;
+    change += d[p].y;
+    change += d[p].z;
+    change += d[p].w;
+  }
+  return change;
+}
+
+// The pieces of the per-PWM state the two-launch scheme keeps beside the caller's arrays (all indexed by PWM):
+//   run[2][n]     run[j & 1] = "still running" behind F_j; launch k reads run[k & 1] (= behind F_(k-2)) and writes
+//                 run[(k - 1) & 1]; the chains of launch k read what it wrote.  Never read and written by one launch.
+//   pwm1[n][4 W]  PWM_j for odd j (even j: the caller's array): launch k reads PWM_(k-2), writes PWM_(k-1) to the other one.
+//   bad[2][n]     bad[k & 1] = "launch k met a weight the scan cannot take" (read by its chains); launch k clears the other.
+struct FusedState {
+  uint32_t* run;       // [2][n]
+  float* pwm0;         // the caller's PWMs (PWM_j, j even)
+  float* pwm1;         // scratch (j odd)
+  uint32_t* bad;       // [2][n]
+  const float* cellsum;  // [n][4 W]: what the chains of the previous launch left
+  int32_t* state;      // the caller's {iterations, running} pairs
+  float* change;       // the caller's `change`
+  uint32_t n;          // PWMs of this batch
+  uint32_t run_stride, bad_stride;  // words between the two copies of run[] / bad[]
+};
+
+// Common head of every workgroup of em_span_fused_kernel: F_(k-1) for PWM pw, or PWM_0 at k = 1.  Leaves the PWM the
+// weights are to be computed from in s_pwm and returns whether the PWM is still running.  `writer`: this workgroup
+// records the step (exactly one workgroup per PWM and launch).
+template <int W>
+__device__ __forceinline__ bool fused_head(const FusedState& fs, uint32_t pw, uint32_t k, float threshold, int max_it, bool writer,
+                                           float* s_pwm, float* s_old, uint32_t t) {
+  constexpr uint32_t CELLS = 4u * W;
+  const uint32_t was_running = fs.run[(size_t)(k & 1u) * fs.run_stride + pw];
+  const float* prev = (k >= 2u && (k & 1u)) ? fs.pwm1 : fs.pwm0;  // PWM_(k-2) (k = 1: PWM_0)
+  float old = 0.0f, sum = 0.0f;
+  if (t < CELLS) {
+    old = prev[(size_t)pw * CELLS + t];
+    if (k >= 2u) sum = fs.cellsum[(size_t)pw * CELLS + t];
+  }
+  if (!was_running) {  // (workgroup-uniform)
+    if (writer && t == 0) {
+      fs.run[(size_t)((k - 1u) & 1u) * fs.run_stride + pw] = 0u;
+      fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
+    }
+    return false;
+  }
+  if (k < 2u) {
+    if (t < CELLS) s_pwm[t] = old;
+    if (writer && t == 0) fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
+    __syncthreads();
+    return true;
+  }
+  if (t < CELLS) {
+    s_pwm[t] = sum;
+    s_old[t] = old;
+  }
+  __syncthreads();
+  const float change = finalize_rows<W>(s_pwm, s_old, t);
+  const int it = (int)k - 1;
+  const bool running = !(change <= threshold || it >= max_it);
+  if (writer) {
+    float* next = (k & 1u) ? fs.pwm0 : fs.pwm1;  // PWM_(k-1)
+    if (t < CELLS) next[(size_t)pw * CELLS + t] = s_pwm[t];
+    if (t == 0) {
+      fs.state[2 * pw] = it;
+      fs.state[2 * pw + 1] = running ? 1 : 0;
+      fs.change[pw] = change;
+      fs.run[(size_t)((k - 1u) & 1u) * fs.run_stride + pw] = running ? 1u : 0u;
+      fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
+    }
+  }
+  return running;
+}
+
 // The weights of a span, as em_weights_kernel computes them, and on the way the span's block sums.  A workgroup per span:
 // thread t = digits 0..3 of x (lane = digits 0..2: a wave stores 64 consecutive floats), 64 x per thread over digits 4..6.
 // The product over the PWM columns in the reference's order ((1*pwm[0][x0])*pwm[1][x1])... (src/peng.cpp:180-197): the
 // factors of digits 0..3 once per thread, digit 4 once per 4 x, ...; the digits above the span, equal for all its x, are
 // still multiplied last, x by x -- float products do not regroup.
-template <int W>
+// HEAD (em_serial_scan = 4): the kernel starts with the previous iteration's finalize step (fused_head: every workgroup
+// of a PWM repeats it from the cell sums the chains stored; `fs`, `k`, `threshold`, `max_it`) instead of reading the PWM
+// and its flags the last chain of the previous launch left -- the chains then need no arrival protocol.
+template <int W, bool HEAD>
 __global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
                                                               const uint32_t* __restrict__ counts, const float* __restrict__ bg,
                                                               float saturation, float* __restrict__ wbuf, uint32_t* __restrict__ bad,
-                                                              float* __restrict__ sums, const uint32_t* __restrict__ bg_range) {
+                                                              float* __restrict__ sums, const uint32_t* __restrict__ bg_range,
+                                                              FusedState fs, uint32_t k, float threshold, int max_it) {
   using G = BlockGeo<W>;
   PENGK_WG_TRACE_BEGIN(1);
   const uint32_t pw = blockIdx.y, sp = blockIdx.x;
-  __shared__ float s_pwm[W * 4];
+  __shared__ __attribute__((aligned(16))) float s_pwm[W * 4], s_old[W * 4];
   __shared__ float part[4][28];
   __shared__ uint32_t s_lean;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  // (the "still running" flag, the PWM and the background's range are asked for TOGETHER -- one memory round trip in front
-  // of the span instead of three, in a kernel of ~20 us; the PWM is used before the flag is looked at for that)
-  int32_t running = state[2 * pw + 1];
-  float mine = pwms[(size_t)pw * W * 4 + (t < W * 4 ? t : 0u)];
   uint32_t bg_lo = bg_range[0], bg_hi = bg_range[1];
-  // (one place where all four are needed, in front of the branch: left to itself the compiler asks for the flag, waits,
-  // branches, asks for the next ...)
-  asm volatile("" : "+s"(running), "+v"(mine), "+s"(bg_lo), "+s"(bg_hi));
-  if (t < W * 4) s_pwm[t] = mine;
-  if (running == 0) return;
-  __syncthreads();
+  if constexpr (HEAD) {
+    if (!fused_head<W>(fs, pw, k, threshold, max_it, sp == 0u, s_pwm, s_old, t)) return;
+    bad = fs.bad + (size_t)(k & 1u) * fs.bad_stride;
+  } else {
+    // (the "still running" flag, the PWM and the background's range are asked for TOGETHER -- one memory round trip in front
+    // of the span instead of three, in a kernel of ~20 us; the PWM is used before the flag is looked at for that)
+    int32_t running = state[2 * pw + 1];
+    float mine = pwms[(size_t)pw * W * 4 + (t < W * 4 ? t : 0u)];
+    // (one place where all four are needed, in front of the branch: left to itself the compiler asks for the flag, waits,
+    // branches, asks for the next ...)
+    asm volatile("" : "+s"(running), "+v"(mine), "+s"(bg_lo), "+s"(bg_hi));
+    if (t < W * 4) s_pwm[t] = mine;
+    if (running == 0) return;
+    __syncthreads();
+  }
   if (t == 0) s_lean = lean_ranges_ok<W>(s_pwm, bg_lo, bg_hi, saturation) ? 1u : 0u;  // (workgroup-uniform: one PWM, one table)
   __syncthreads();
   const bool lean = s_lean != 0u;
@@ -1157,8 +1271,9 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
                                                                             seqsum::BlockRecord* __restrict__ rec,
                                                                             const uint32_t* __restrict__ bad, uint32_t n_pwm,
                                                                             const float* __restrict__ sums, uint32_t skew,
-                                                                            uint32_t extra_wgs) {
+                                                                            uint32_t extra_wgs, const uint32_t* __restrict__ run_now) {
   using G = BlockGeo<W>;
+  // (run_now: the PWMs' "still running" flags where the weights kernel keeps them itself (em_serial_scan = 4); else state[])
   // (consecutive workgroups go to consecutive XCDs: a PWM's spans, and behind them its chains, stay on one -- as in
   // em_fold_scan_kernel; 1000 PWMs x 10 iterations: 35.5 ms, with PWM = blockIdx.y 37.5)
   PENGK_WG_TRACE_BEGIN(2);
@@ -1176,7 +1291,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
     const uint32_t xi = lin, xslot = xi >> 3;
     constexpr uint32_t XW = (G::CELLS + 3u) / 4u;  // workgroups per PWM
     const uint32_t pw = (xi & 7u) + 8u * (xslot / XW), cell = 4u * (xslot % XW) + wave;
-    if (pw >= n_pwm || wave >= 4u || cell >= G::CELLS || state[2 * pw + 1] == 0 || bad[pw]) return;
+    if (pw >= n_pwm || wave >= 4u || cell >= G::CELLS || (run_now ? run_now[pw] == 0u : state[2 * pw + 1] == 0) || bad[pw]) return;
     seqsum::lds_float* buf = (seqsum::lds_float*)span + wave * seqsum::BLOCK;
     const float* w = wbuf + (size_t)pw * G::NP;
     seqsum::Row mine;
@@ -1219,7 +1334,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
   }
   // (the flags are looked at behind the estimates -- which touch nothing but this workgroup's LDS -- so that no branch
   // stands between the span's loads and the estimates' loads: a workgroup of a PWM that is done leaves a little later)
-  const int32_t running = state[2 * pw + 1];
+  const int32_t running = run_now ? (int32_t)run_now[pw] : state[2 * pw + 1];
   const uint32_t flagged = bad[pw];
   constexpr uint32_t TASKS = (G::CELLS + SPAN_EVAL_WAVES - 1u) / SPAN_EVAL_WAVES;  // per wave
   seqsum::BlockRecord* cells = rec + (size_t)pw * G::CELLS * G::NBLK;
@@ -1401,9 +1516,20 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
 // costs time and never the result (seqsum.h: exactness does not rest on the estimates).  So neither an unexpected
 // dispatch order nor a lost workgroup can hang the launch.  Test hook em_test_lookback = n: every n-th workgroup acts as
 // if its deadline had passed.
+// per-call counters of what the chains met (pengk_get_info "em_*"): fetched, mispredicted, restaged, restaged_waits
+// (seqsum::WalkCounts), blocks passed by their row records, blocks whose row records did not hold (seqsum::Walk2Counts);
+// behind them in the same allocation: the background table's {min, max}
+constexpr int EM_COUNTERS = 6;
 struct FusedGeo {
   static constexpr uint32_t THREADS = 512, WAVES = 8, CHUNK = 64;
   static constexpr unsigned long long LOOKBACK_TICKS = 50000ull;  // 500 us
+  static constexpr float ROW_MARGIN = 1.0f / 2048.0f;  // what an estimate is trusted to when it names a ROW's binade (seqsum.h, row_record)
+};
+// bytes of row records (seqsum.h, "rows ahead of their chain") a cell's blocks may leave per iteration: 2 KiB + 256 B per
+// raw row and block; a block that finds no room is folded from the table
+template <int W>
+struct RowArea {
+  static constexpr uint32_t BYTES = W <= 10 ? 64u * 1024u : 256u * 1024u;
 };
 template <int W>
 struct LookGeo {
@@ -1419,111 +1545,6 @@ __device__ __forceinline__ unsigned long long look_word(uint32_t epoch, float v)
 }
 __device__ __forceinline__ unsigned long long look_load(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// What F_j, the finalize step of iteration j, makes of a PWM: the reference's float32 epilogue -- normalise rows
-// (src/peng.cpp:129, src/iupac_pattern.cpp:291-303), change = sum |new - old| in p-major order (:132-137) -- from the cell
-// sums in s_new[0 .. 4 W) and the previous PWM in s_old[0 .. 4 W) (LDS; every thread of the workgroup calls it between
-// two barriers of its own).  The new PWM is left in s_new, the cells' |new - old| in s_old; returns `change` (the same
-// value in every thread: each adds up the 4 W differences itself, in p-major order, from 16-byte LDS reads).
-template <int W>
-__device__ __forceinline__ float finalize_rows(float* s_new, float* s_old, uint32_t t) {
-  typedef seqsum::f4 f4;
-  float mine = 0.0f, diff = 0.0f;
-  if (t < 4u * W) {
-    const f4 row = reinterpret_cast<const f4*>(s_new)[t >> 2];
-    float sum = 0.0f;
-    sum += row.x;
-    sum += row.y;
-    sum += row.z;
-    sum += row.w;
-    mine = s_new[t] / sum;
-    diff = fabsf(mine - s_old[t]);
-  }
-  __syncthreads();
-  if (t < 4u * W) {
-    s_new[t] = mine;
-    s_old[t] = diff;
-  }
-  __syncthreads();
-  float change = 0.0f;
-  f4 d[W];
-#pragma unroll
-  for (int p = 0; p < W; ++p) d[p] = reinterpret_cast<const f4*>(s_old)[p];
-#pragma unroll
-  for (int p = 0; p < W; ++p) {
-    change += d[p].x;
-    change += d[p].y;
-    change += d[p].z;
-    change += d[p].w;
-  }
-  return change;
-}
-
-// The pieces of the per-PWM state the two-launch scheme keeps beside the caller's arrays (all indexed by PWM):
-//   run[2][n]     run[j & 1] = "still running" behind F_j; launch k reads run[k & 1] (= behind F_(k-2)) and writes
-//                 run[(k - 1) & 1]; the chains of launch k read what it wrote.  Never read and written by one launch.
-//   pwm1[n][4 W]  PWM_j for odd j (even j: the caller's array): launch k reads PWM_(k-2), writes PWM_(k-1) to the other one.
-//   bad[2][n]     bad[k & 1] = "launch k met a weight the scan cannot take" (read by its chains); launch k clears the other.
-struct FusedState {
-  uint32_t* run;       // [2][n]
-  float* pwm0;         // the caller's PWMs (PWM_j, j even)
-  float* pwm1;         // scratch (j odd)
-  uint32_t* bad;       // [2][n]
-  const float* cellsum;  // [n][4 W]: what the chains of the previous launch left
-  int32_t* state;      // the caller's {iterations, running} pairs
-  float* change;       // the caller's `change`
-  uint32_t n;          // PWMs of this batch
-  uint32_t run_stride, bad_stride;  // words between the two copies of run[] / bad[]
-};
-
-// Common head of every workgroup of em_span_fused_kernel: F_(k-1) for PWM pw, or PWM_0 at k = 1.  Leaves the PWM the
-// weights are to be computed from in s_pwm and returns whether the PWM is still running.  `writer`: this workgroup
-// records the step (exactly one workgroup per PWM and launch).
-template <int W>
-__device__ __forceinline__ bool fused_head(const FusedState& fs, uint32_t pw, uint32_t k, float threshold, int max_it, bool writer,
-                                           float* s_pwm, float* s_old, uint32_t t) {
-  constexpr uint32_t CELLS = 4u * W;
-  const uint32_t was_running = fs.run[(size_t)(k & 1u) * fs.run_stride + pw];
-  const float* prev = (k >= 2u && (k & 1u)) ? fs.pwm1 : fs.pwm0;  // PWM_(k-2) (k = 1: PWM_0)
-  float old = 0.0f, sum = 0.0f;
-  if (t < CELLS) {
-    old = prev[(size_t)pw * CELLS + t];
-    if (k >= 2u) sum = fs.cellsum[(size_t)pw * CELLS + t];
-  }
-  if (!was_running) {  // (workgroup-uniform)
-    if (writer && t == 0) {
-      fs.run[(size_t)((k - 1u) & 1u) * fs.run_stride + pw] = 0u;
-      fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
-    }
-    return false;
-  }
-  if (k < 2u) {
-    if (t < CELLS) s_pwm[t] = old;
-    if (writer && t == 0) fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
-    __syncthreads();
-    return true;
-  }
-  if (t < CELLS) {
-    s_pwm[t] = sum;
-    s_old[t] = old;
-  }
-  __syncthreads();
-  const float change = finalize_rows<W>(s_pwm, s_old, t);
-  const int it = (int)k - 1;
-  const bool running = !(change <= threshold || it >= max_it);
-  if (writer) {
-    float* next = (k & 1u) ? fs.pwm0 : fs.pwm1;  // PWM_(k-1)
-    if (t < CELLS) next[(size_t)pw * CELLS + t] = s_pwm[t];
-    if (t == 0) {
-      fs.state[2 * pw] = it;
-      fs.state[2 * pw + 1] = running ? 1 : 0;
-      fs.change[pw] = change;
-      fs.run[(size_t)((k - 1u) & 1u) * fs.run_stride + pw] = running ? 1u : 0u;
-      fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
-    }
-  }
-  return running;
 }
 
 // One weight, the reference's operations (src/peng.cpp:124-125, 180-197): x = the pattern, pr over the PWM's columns in
@@ -1544,7 +1565,8 @@ __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_
                                                                           float* __restrict__ wbuf, seqsum::BlockRecord* __restrict__ rec,
                                                                           unsigned long long* __restrict__ look, uint32_t epoch,
                                                                           const uint32_t* __restrict__ bg_range, uint32_t skew,
-                                                                          uint32_t test_lookback, uint32_t extra_wgs) {
+                                                                          uint32_t test_lookback, uint32_t extra_wgs,
+                                                                          char* __restrict__ row_area, uint32_t* __restrict__ row_cursor) {
   using G = BlockGeo<W>;
   using LG = LookGeo<W>;
   constexpr uint32_t CELLS = G::CELLS, WAVES = FusedGeo::WAVES;
@@ -1835,8 +1857,8 @@ __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_
     if (b == 0u && extra_wgs != 0u) continue;  // (folded from zero by the workgroups in front of the spans')
     seqsum::BlockRecord* r = cells + (size_t)cell * G::NBLK + b;
     uint32_t e = seqsum::NO_BINADE;
+    float before = 0.0f;
     if (est_ok) {
-      float before = 0.0f;
 #pragma unroll
       for (uint32_t w = 0; w < WAVES; ++w) before += s_look[0][w][cell] + s_look[1][w][cell];
       float own = s_cell[cell];
@@ -1846,12 +1868,67 @@ __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_
       }
       e = block_binade((double)before, (double)before + (double)own, skew, cell * G::NBLK + b);
     }
-    if (e == seqsum::NO_BINADE) {
+    const bool by_rows = e == seqsum::NO_BINADE && est_ok && row_area != nullptr;
+    if (e == seqsum::NO_BINADE && !by_rows) {
       if (lane == 0) r->e = seqsum::NO_BINADE;
       continue;
     }
     seqsum::Row mine;
-    span_row<W>(span, p, j, lane, mine);
+    span_row<W>(span, p, j, lane, mine);  // (once per task, whichever way the block goes: the six ways a row lies in the span are the bulk of this loop's code)
+    if (by_rows) {
+      // No binade for the block as a whole -- block 0, where the sum climbs from zero, or a block in which it passes a
+      // power of two: its ROWS are evaluated instead, each under the binade its own estimate names and the one above, and
+      // the rows that cannot name one leave their terms behind (seqsum.h, "rows ahead of their chain").  Where to: the
+      // cell's area, by a cursor (one returning atomic per such block: ~6 per cell and iteration).
+      bool done = false;
+      {
+        const bool wrong = skew != 0u && (((cell * G::NBLK + b) * 64u + lane) * 2654435761u >> 16) % skew == 0u;
+        const seqsum::RowClass rc = seqsum::row_classify(mine, lane, before, FusedGeo::ROW_MARGIN, wrong);
+        const bool raw = !rc.certain;
+        const unsigned long long rawmask = __builtin_amdgcn_ballot_w64(raw);
+        const uint32_t n_raw = (uint32_t)__builtin_popcountll(rawmask);
+        if (n_raw <= seqsum::MAX_RAW_ROWS) {
+          const uint32_t bytes = seqsum::ROW_RECORD_BYTES + 256u * n_raw;
+          uint32_t off = 0u;
+          // (the place is asked for as soon as the size is known: the atomic's round trip lies behind the rows' evaluation)
+          if (lane == 0) off = __hip_atomic_fetch_add(row_cursor + (size_t)pw * CELLS + cell, bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          seqsum::RowRecord rr = seqsum::row_record(mine, rc);
+          off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+          if (off + bytes <= RowArea<W>::BYTES) {
+            char* slot = row_area + ((size_t)pw * CELLS + cell) * RowArea<W>::BYTES + off;
+            const uint32_t ridx = __builtin_amdgcn_mbcnt_hi((uint32_t)(rawmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rawmask, 0u));
+            if (raw) rr.info = (rr.info & 0xFFu) | (ridx << 8);
+            uint4 ha, hb;
+            ha.x = rr.e;
+            ha.y = __float_as_uint(rr.d0);
+            ha.z = __float_as_uint(rr.d1);
+            ha.w = rr.info;
+            hb.x = __float_as_uint(rr.u0);
+            hb.y = __float_as_uint(rr.u1);
+            hb.z = 0u;
+            hb.w = 0u;
+            reinterpret_cast<uint4*>(slot)[2u * lane] = ha;
+            reinterpret_cast<uint4*>(slot)[2u * lane + 1u] = hb;
+            if (raw) {
+              seqsum::f4* dst = reinterpret_cast<seqsum::f4*>(slot + seqsum::ROW_RECORD_BYTES + 256u * ridx);
+#pragma unroll
+              for (uint32_t q = 0; q < 16u; ++q) dst[q] = mine.q[q];
+            }
+            if (lane == 0) {
+              seqsum::BlockRecord out;
+              out.e = seqsum::ROWS;
+              out.d0 = __uint_as_float(off);
+              out.d1 = __uint_as_float(n_raw);
+              out.pad = 0u;
+              *r = out;
+            }
+            done = true;
+          }
+        }
+      }
+      if (!done && lane == 0) r->e = seqsum::NO_BINADE;
+      continue;
+    }
     float d0, d1;
     const bool ok = seqsum::block_increments(mine, lane, seqsum::bases_of_binade(e), d0, d1);
     if (lane == 0) {
@@ -1868,18 +1945,23 @@ __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_
 
 // The chains of a launch of em_span_fused_kernel: one wave per cell; the cell's sum is stored for the next launch's head
 // (or em_fused_finish_kernel) -- a plain store, the kernel boundary orders it.
-template <int W>
+// BY_ROWS: blocks may have left row records (seqsum.h, walk_chain_rows: one buffer for the blocks folded from the table and
+// one for the records); else walk_chain with its two block buffers.
+template <int W, bool BY_ROWS>
 __global__ __launch_bounds__(64) void em_chain_store_kernel(const uint32_t* __restrict__ run, const uint32_t* __restrict__ bad,
                                                             const float* __restrict__ wbuf, const seqsum::BlockRecord* __restrict__ rec,
                                                             float* __restrict__ cellsum, uint32_t n_pwm,
-                                                            unsigned long long* __restrict__ counters) {
+                                                            unsigned long long* __restrict__ counters,
+                                                            const char* __restrict__ row_area, uint32_t* __restrict__ row_cursor) {
   using G = BlockGeo<W>;
   PENGK_WG_TRACE_BEGIN(3);
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
   if (pw >= n_pwm) return;
-  __shared__ __attribute__((aligned(16))) float lds[seqsum::WALK_LDS_FLOATS];
-  seqsum::WalkCounts wc;
+  __shared__ __attribute__((aligned(16))) float lds[BY_ROWS ? seqsum::WALK2_LDS_FLOATS : seqsum::WALK_LDS_FLOATS];
+  seqsum::Walk2Counts wc;
+  seqsum::WalkCounts wc1;
+  const char* rows = BY_ROWS ? row_area + ((size_t)pw * G::CELLS + cell) * RowArea<W>::BYTES : nullptr;
   const uint32_t lane = threadIdx.x;
   const seqsum::BlockRecord* r = rec + ((size_t)pw * G::CELLS + cell) * G::NBLK;
   // (the PWM's two flags and the chain's first 64 records are asked for together: one memory round trip at the head of
@@ -1899,18 +1981,27 @@ __global__ __launch_bounds__(64) void em_chain_store_kernel(const uint32_t* __re
   } else if ((cell >> 2) == 0u) {
     EmTerms0<W> src0{w, cell & 3u};
     src0.bind_stage(lane);
-    s = seqsum::walk_chain(src0, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
+    if constexpr (BY_ROWS) s = seqsum::walk_chain_rows(src0, r, first, G::NBLK, rows, (seqsum::lds_float*)lds, lane, wc);
+    else s = seqsum::walk_chain(src0, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc1);
   } else {
     EmTerms<W> src{w, cell >> 2, cell & 3u};
     src.bind_stage(lane);
-    s = seqsum::walk_chain(src, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
+    if constexpr (BY_ROWS) s = seqsum::walk_chain_rows(src, r, first, G::NBLK, rows, (seqsum::lds_float*)lds, lane, wc);
+    else s = seqsum::walk_chain(src, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc1);
+  }
+  if constexpr (!BY_ROWS) {
+    wc.fetched = wc1.fetched;
+    wc.mispredicted = wc1.mispredicted;
   }
   if (lane == 0) {
     cellsum[(size_t)pw * G::CELLS + cell] = s;
+    if (BY_ROWS) row_cursor[(size_t)pw * G::CELLS + cell] = 0u;  // (the next launch's blocks start over in the cell's area)
+    if (wc1.restaged) __hip_atomic_fetch_add(counters + 2, (unsigned long long)wc1.restaged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc1.restaged_waits) __hip_atomic_fetch_add(counters + 3, (unsigned long long)wc1.restaged_waits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wc.fetched) __hip_atomic_fetch_add(counters + 0, (unsigned long long)wc.fetched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wc.mispredicted) __hip_atomic_fetch_add(counters + 1, (unsigned long long)wc.mispredicted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wc.restaged) __hip_atomic_fetch_add(counters + 2, (unsigned long long)wc.restaged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wc.restaged_waits) __hip_atomic_fetch_add(counters + 3, (unsigned long long)wc.restaged_waits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.rows) __hip_atomic_fetch_add(counters + 4, (unsigned long long)wc.rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.rows_failed) __hip_atomic_fetch_add(counters + 5, (unsigned long long)wc.rows_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   PENGK_WG_TRACE_END(wc.fetched > 255u ? 255u : wc.fetched, lin);
 }
@@ -1955,7 +2046,7 @@ __global__ __launch_bounds__(256) void em_fused_setup_kernel(uint32_t n, int W, 
                                                              unsigned long long* __restrict__ counters, uint32_t* __restrict__ bg_range,
                                                              uint32_t lean, uint32_t* __restrict__ bad, uint32_t bad_words) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i < 4u) counters[i] = 0ull;
+  if (i < (uint32_t)EM_COUNTERS) counters[i] = 0ull;
   if (i == 0) {
     bg_range[0] = lean ? 0xFFFFFFFFu : 0u;
     bg_range[1] = lean ? 0u : 0xFFFFFFFFu;
@@ -2066,7 +2157,6 @@ namespace {
 // kernel has run, so that chains run beside weights, was measured twice: no gain, behind the chains a loss --
 // profiles/r04_em_kernels.log.)
 // (PWMs are independent; every batch has its own tables, records and sums.)  `budget` = bytes of weight tables in flight.
-constexpr int EM_COUNTERS = 4;  // fetched, mispredicted, restaged, restaged_waits (seqsum::WalkCounts); behind them: the background table's {min, max}
 // What a pengk_em call in this mode starts from, in ONE launch (four to five memsets took 8-25 us apiece in front of the
 // first weights kernel): the chains' counters zero, the background's range {all ones, 0} for em_bg_range_kernel's min /
 // max -- or {0, all ones}, a range nothing accepts, with the lean division off --, every lane's flags and arrival
@@ -2160,8 +2250,9 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
           uint32_t* done = bad + batch;
           float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * blocks_b);
           seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
-          hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
-                             d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums, (const uint32_t*)bg_range);
+          hipLaunchKernelGGL((em_weights_span_kernel<W, false>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
+                             d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums, (const uint32_t*)bg_range, FusedState{}, 0u,
+                             0.0f, 0);
           if (!B::PREDICT_IN_EVAL)
             hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec,
                                (uint32_t)ctx->em_test_skew);
@@ -2171,7 +2262,7 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
           const unsigned gx = 1024u;
           hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
                              d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums, (uint32_t)ctx->em_test_skew,
-                             (uint32_t)extra_wgs);
+                             (uint32_t)extra_wgs, (const uint32_t*)nullptr);
           hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, d_state + 2 * first, (const float*)tables,
                              (const seqsum::BlockRecord*)rec, partials, bad, (uint32_t)nb, done, d_pwms + (size_t)first * W * 4,
                              d_change + first, threshold, max_it, ctx->d_em_counters);
@@ -2195,9 +2286,11 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
 
 // The serial mode as two launches per iteration (em_serial_scan = 3; W = 10, 12): em_span_fused_kernel + em_chain_store_kernel
 // per batch of PWMs, batches taking turns on the lanes as in launch_serial_ahead, one em_fused_finish_kernel per batch.
+// `split` (em_serial_scan = 4): three launches per iteration as in launch_serial_ahead -- weights, block evaluation, chains --
+// but with the finalize step at the head of the weights kernel and chains that store their sums plainly.
 template <int W>
 int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
-                        const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change, size_t budget) {
+                        const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change, size_t budget, bool split) {
   using B = BlockGeo<W>;
   using LG = LookGeo<W>;
   const size_t np = (size_t)1 << (2 * W);
@@ -2212,10 +2305,13 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   if (batch > 16384) batch = 16384;  // (grid size; far beyond any budget)
   // per lane: tables | records | look-back words | cell sums, "bad weight" flags.  Per call: run[2][n] | PWM_odd[n][4 W]
   const size_t tables_b = (size_t)batch * np * sizeof(float);
-  const size_t rec_b = ((size_t)batch * B::CELLS * B::NBLK * sizeof(seqsum::BlockRecord) + 255) / 256 * 256;
+  const size_t sums_b = split ? ((size_t)batch * B::CELLS * B::NBLK * sizeof(float) + 255) / 256 * 256 : 0;  // (split: the plain block sums in front of the records)
+  const size_t rec_b = sums_b + ((size_t)batch * B::CELLS * B::NBLK * sizeof(seqsum::BlockRecord) + 255) / 256 * 256;
   const size_t look_b = ((size_t)batch * LG::WORDS_PER_PWM * sizeof(unsigned long long) + 255) / 256 * 256;
   const size_t flags_at = ((size_t)batch * B::CELLS * sizeof(float) + 255) / 256 * 256;
-  const size_t small_b = (flags_at + (size_t)2 * batch * sizeof(uint32_t) + 255) / 256 * 256;
+  const size_t cursor_at = (flags_at + (size_t)2 * batch * sizeof(uint32_t) + 255) / 256 * 256;  // (the row records' cursors: cleared with the flags)
+  const size_t small_b = (cursor_at + (size_t)batch * B::CELLS * sizeof(uint32_t) + 255) / 256 * 256;
+  const size_t rows_b = ctx->em_rows && !split ? (size_t)batch * B::CELLS * RowArea<W>::BYTES : 0;
   const size_t run_at = lanes * small_b;
   const size_t pwm1_at = (run_at + (size_t)2 * n_pwm * sizeof(uint32_t) + 255) / 256 * 256;
   int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, lanes * tables_b);
@@ -2224,6 +2320,10 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   if (rc) return rc;
   rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes, lanes * rec_b);
   if (rc) return rc;
+  if (rows_b) {
+    rc = ensure_scratch(ctx, &ctx->d_em_rows, &ctx->em_rows_bytes, lanes * rows_b);
+    if (rc) return rc;
+  }
   {
     // the look-back words carry the epoch of the launch that wrote them: a fresh buffer starts from zero (no launch has
     // epoch 0), and so does a counter that has gone round
@@ -2276,10 +2376,13 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
           const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
           hipStream_t st = streams[l];
           float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_tables) + l * tables_b);
-          seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * rec_b);
+          float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * rec_b);
+          seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * rec_b + sums_b);
           unsigned long long* look = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->d_em_look) + l * look_b);
           float* cellsum = reinterpret_cast<float*>(small + l * small_b);
           uint32_t* bad = reinterpret_cast<uint32_t*>(small + l * small_b + flags_at);
+          uint32_t* cursor = reinterpret_cast<uint32_t*>(small + l * small_b + cursor_at);
+          char* rows = rows_b ? reinterpret_cast<char*>(ctx->d_em_rows) + l * rows_b : nullptr;
           FusedState fs;
           fs.run = run + first;
           fs.pwm0 = d_pwms + (size_t)first * W * 4;
@@ -2297,17 +2400,46 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
           }
           const uint32_t k = (uint32_t)it;
           const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
+          const uint32_t* run_now = run + (size_t)((k - 1u) & 1u) * n_pwm + first;  // behind this launch's head
+          const uint32_t* bad_now = bad + (size_t)(k & 1u) * batch;
+          if (split) {
+            hipLaunchKernelGGL((em_weights_span_kernel<W, true>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, (const float*)nullptr,
+                               (const int32_t*)nullptr, d_counts, d_bg, saturation, tables, (uint32_t*)nullptr, sums, (const uint32_t*)bg_range, fs,
+                               k, threshold, max_it);
+            const uint64_t xwgs = (uint64_t)groups * ((B::CELLS + 3) / 4), swgs = xwgs + (uint64_t)groups * B::SPANS;
+            hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(1024u, (unsigned)((swgs + 1023u) / 1024u)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
+                               (const int32_t*)nullptr, (const float*)tables, rec, bad_now, (uint32_t)nb, (const float*)sums,
+                               (uint32_t)ctx->em_test_skew, (uint32_t)xwgs, run_now);
+            hipLaunchKernelGGL((em_chain_store_kernel<W, false>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
+                               (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters,
+                               (const char*)nullptr, cursor);
+            continue;
+          }
           // block 0 of every cell: by workgroups in front of the spans' (option em_block0 = 1), or left to its chain
           const uint64_t extra_wgs = ctx->em_block0 ? (uint64_t)groups * ((B::CELLS + 3) / 4) : 0;
           const uint64_t wgs = extra_wgs + (uint64_t)groups * B::SPANS;
           const unsigned gx = 1024u;
           const uint32_t epoch = ++ctx->em_epoch;
+          // The lanes out of step: lane l's first span kernel waits for lane l - 1's -- started together, the lanes run their
+          // span kernels side by side (each at half the chip) and then their chains side by side; one behind the other, a
+          // lane's chains -- waves that wait for memory -- run beside the other lane's arithmetic (option em_stagger).
+          if (ctx->em_stagger && it == 1 && round0 == 0 && l > 0 && ctx->em_step[l - 1])
+            PENGK_HIP(hipStreamWaitEvent(st, ctx->em_step[l - 1], 0));
           hipLaunchKernelGGL((em_span_fused_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(FusedGeo::THREADS), 0, st, fs, k,
                              threshold, max_it, d_counts, d_bg, saturation, tables, rec, look, epoch, (const uint32_t*)bg_range,
-                             (uint32_t)ctx->em_test_skew, (uint32_t)ctx->em_test_lookback, (uint32_t)extra_wgs);
-          hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st,
-                             (const uint32_t*)(run + (size_t)((k - 1u) & 1u) * n_pwm + first), (const uint32_t*)(bad + (size_t)(k & 1u) * batch),
-                             (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters);
+                             (uint32_t)ctx->em_test_skew, (uint32_t)ctx->em_test_lookback, (uint32_t)extra_wgs, rows, cursor);
+          if (ctx->em_stagger && it == 1 && round0 == 0 && l + 1 < lanes) {
+            if (!ctx->em_step[l]) PENGK_HIP(hipEventCreateWithFlags(&ctx->em_step[l], hipEventDisableTiming));
+            PENGK_HIP(hipEventRecord(ctx->em_step[l], st));
+          }
+          if (rows)
+            hipLaunchKernelGGL((em_chain_store_kernel<W, true>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
+                               (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters,
+                               (const char*)rows, cursor);
+          else
+            hipLaunchKernelGGL((em_chain_store_kernel<W, false>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
+                               (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters,
+                               (const char*)rows, cursor);
         }
       }
       PENGK_HIP(hipGetLastError());
@@ -2364,8 +2496,9 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
   // blocks evaluated ahead of the chain (W >= 10): span-major weights with block sums, no second copy of the table
   if constexpr (SCAN && W >= 10) {
     if constexpr (W <= 12) {  // (W = 14: 16384 spans per PWM would take a third look-back level; it keeps the three launches)
-      if (scan && ctx->em_serial_scan == 3)
-        return launch_serial_fused<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change, budget);
+      if (scan && ctx->em_serial_scan >= 3)
+        return launch_serial_fused<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change, budget,
+                                      ctx->em_serial_scan == 4);
     }
     if (scan && ctx->em_serial_scan >= 2)
       return launch_serial_ahead<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change, budget);

@@ -14,23 +14,25 @@ sys.path.insert(0, ROOT)
 import peng_motif_amd as pk  # noqa: E402
 
 
-def run(ctx, W, pwms, counts, bgd, thr, its, scan, skew=0, lookback=0, streams=2, budget=0):
+def run(ctx, W, pwms, counts, bgd, thr, its, scan, skew=0, lookback=0, streams=2, budget=0, rows=1):
     ctx.set_option("em_fast", 2)
     ctx.set_option("em_serial_scan", scan)
     ctx.set_option("em_test_skew", skew)
     ctx.set_option("em_test_lookback", lookback)
     ctx.set_option("em_overlap", streams)
     ctx.set_option("em_table_budget_mb", budget)
+    ctx.set_option("em_rows", rows)
     try:
         t = time.time()
         out = ctx.em(W, pwms.copy(), counts, bgd, 1e4, thr, its)
         dt = time.time() - t
-        met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks")}
+        met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks", "row_blocks", "row_failed")}
     finally:
         ctx.set_option("em_test_skew", 0)
         ctx.set_option("em_test_lookback", 0)
         ctx.set_option("em_overlap", 2)
         ctx.set_option("em_table_budget_mb", 0)
+        ctx.set_option("em_rows", 1)
         ctx.set_option("em_serial_scan", 2)
         ctx.set_option("em_fast", 1)
     return out, dt, met
@@ -58,13 +60,14 @@ def main():
         thr = float(np.median(ref0[2]))
         for its, th in ((3, 0.0), (6, thr), (1, 0.0), (0, 0.0), (2, 1e9)):
             ref, _, _ = run(ctx, W, pwms, counts, bgd, th, its, 0)
-            for scan, skew, lb, streams, budget in ((2, 0, 0, 2, 0), (3, 0, 0, 2, 0), (3, 0, 0, 1, 0), (3, 2, 0, 2, 0), (3, 0, 3, 2, 0),
-                                                   (3, 5, 7, 3, 0), (3, 0, 1, 2, 0), (3, 0, 0, 2, 32 if W == 10 else 256)):
-                got, dt, met = run(ctx, W, pwms, counts, bgd, th, its, scan, skew, lb, streams, budget)
+            for scan, skew, lb, streams, budget, rows in ((2, 0, 0, 2, 0, 1), (3, 0, 0, 2, 0, 1), (3, 0, 0, 2, 0, 0), (3, 0, 0, 1, 0, 1), (3, 2, 0, 2, 0, 1), (3, 0, 3, 2, 0, 1),
+                                                   (3, 5, 7, 3, 0, 1), (3, 0, 1, 2, 0, 1), (3, 0, 0, 2, 32 if W == 10 else 256, 1), (3, 1, 0, 2, 0, 1),
+                                                   (4, 0, 0, 2, 0, 1), (4, 3, 0, 1, 0, 1), (4, 0, 0, 3, 32 if W == 10 else 256, 1)):
+                got, dt, met = run(ctx, W, pwms, counts, bgd, th, its, scan, skew, lb, streams, budget, rows)
                 ok = same(got, ref)
                 bad += not ok
-                print("W=%d its=%d thr=%g scan=%d skew=%d lookback=%d streams=%d budget=%d: %s  %.1f ms  %s iters=%s" % (
-                    W, its, th, scan, skew, lb, streams, budget, "ok" if ok else "DIFFERENT", dt * 1e3, met,
+                print("W=%d its=%d thr=%g scan=%d skew=%d lookback=%d streams=%d budget=%d rows=%d: %s  %.1f ms  %s iters=%s" % (
+                    W, its, th, scan, skew, lb, streams, budget, rows, "ok" if ok else "DIFFERENT", dt * 1e3, met,
                     sorted(set(got[1].tolist()))), flush=True)
     # a degenerate PWM (zero entries -> 0/0 weights): the plain-loop path
     W = 10
@@ -77,10 +80,11 @@ def main():
     pwms = rng.dirichlet(np.ones(4), size=(3, W)).astype(np.float32)
     pwms[1, 3] = (0.0, 0.5, 0.5, 0.0)
     ref, _, _ = run(ctx, W, pwms, counts, bgd, 0.0, 2, 0)
-    got, dt, met = run(ctx, W, pwms, counts, bgd, 0.0, 2, 3)
-    ok = got[0].tobytes() == ref[0].tobytes() and got[1].tolist() == ref[1].tolist()
-    bad += not ok
-    print("degenerate W=10: %s %.1f ms nan=%d" % ("ok" if ok else "DIFFERENT", dt * 1e3, int(np.isnan(got[0]).sum())), flush=True)
+    for scan in (3, 4):
+        got, dt, met = run(ctx, W, pwms, counts, bgd, 0.0, 2, scan)
+        ok = got[0].tobytes() == ref[0].tobytes() and got[1].tolist() == ref[1].tolist()
+        bad += not ok
+        print("degenerate W=10 scan=%d: %s %.1f ms nan=%d" % (scan, "ok" if ok else "DIFFERENT", dt * 1e3, int(np.isnan(got[0]).sum())), flush=True)
     ctx.close()
     print("FAILURES:", bad)
     sys.exit(1 if bad else 0)
