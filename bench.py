@@ -59,7 +59,7 @@ def parse_args():
     ap.add_argument("--em-stress-pwms", type=int, default=1000,
                     help="BASELINE configs[4]: EM-only stress on this many top-count seeds of the PLUS table (split over ranks); 0 = skip")
     ap.add_argument("--em-serial-scan", type=int, default=2,
-                    help="pengk option em_serial_scan: 2 = scan with its blocks evaluated ahead of the chain (default), 1 = scan, 0 = fold")
+                    help="the serial EM's scheme (pengk_test_em_generation): 2 = blocks evaluated ahead of the chain, three launches per iteration (default), 3 = two launches, 1 = scan block after block, 0 = fold")
     ap.add_argument("--em-overlap", type=int, default=0,
                     help="pengk option em_overlap: streams the serial EM's batches of PWMs take turns on (1..4; 0 = the library's default)")
     ap.add_argument("--em-table-budget-mb", type=int, default=0,
@@ -295,7 +295,7 @@ def pipelined_leg(rt, args, leg, W, both, steps, warmup):
     ctx2 = pk.Context(dev.index)
     pk._check(lib.pengk_set_stream(ctx2.h, s1.cuda_stream))
     ctx2.set_option("em_fast", args.em_fast)
-    ctx2.set_option("em_serial_scan", args.em_serial_scan)
+    ctx2.test_em_generation(args.em_serial_scan)
     sets = []
     for _ in range(2):
         sets.append(dict(counts=torch.empty(NP, dtype=torch.int32, device=dev), scal=torch.zeros(85, dtype=torch.int64, device=dev),
@@ -513,7 +513,7 @@ def main():
     ctx.set_option("count_impl", args.count_impl)
     ctx.set_option("em_fast", args.em_fast)
     ctx.set_option("em_table_budget_mb", args.em_table_budget_mb)
-    ctx.set_option("em_serial_scan", args.em_serial_scan)
+    ctx.test_em_generation(args.em_serial_scan)
     if args.em_overlap:
         ctx.set_option("em_overlap", args.em_overlap)
 
@@ -740,8 +740,9 @@ def main():
                 # the mode the CLI ships and the bench step times: pinned to the reference's PWMs bit for bit
                 ev_s = em_stress[0] * args.em_iters * NP / (em_stress[2] * 1e-3)
                 out["roofline_em"]["parity_mode"] = {
-                    "kernel": ("em_weights_span_kernel<%d> + em_span_eval_kernel<%d> + em_chain_kernel<%d>" % (W, W, W)
+                    "kernel": ("em_weights_span_kernel<%d> + em_span_eval_kernel<%d> + em_chain_store_kernel<%d>" % (W, W, W)
                                if W >= 10 and args.em_serial_scan == 2 else
+                               "em_span_fused_kernel<%d> + em_chain_store_kernel<%d>" % (W, W) if W >= 10 and args.em_serial_scan == 3 else
                                "em_weights_kernel<%d> + em_fold_scan_kernel<%d>" % (W, W)) + " (K5, serial bit-exact mode, same PWMs)",
                     "ms": round(em_stress[2], 4), "evals_per_s": round(ev_s, 1),
                     "achieved": round(ev_s * (2 * W + 4) / 1e12, 3), "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",

@@ -244,17 +244,20 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  *      weight is summed by a plain loop).  What a caller needs when discrete decisions follow (motif merging compares
  *      similarity scores that are exactly tied in real arithmetic for reverse-complement twins); the CLI's default.
  *      Options of this mode (pengk_set_option):
- *        "em_serial_scan"      how a cell's 4^(W-1) additions are carried out -- always the reference's sum, bit for bit:
- *                              2 (default) the scan with its blocks of 4096 terms evaluated AHEAD of the chain: all
- *                              blocks of all cells at once, each under the binade a prefix of plain block sums predicts
- *                              for it, then one addition per block along the chain (W >= 10; below: as 1);
- *                              1 the scan, block after block;  0 one dependent addition after the other.
- *        "em_overlap"          with "em_serial_scan" = 2: streams the batches of PWMs take turns on, 1..4 (default 2; the
+ *      How the sum is carried out: W >= 10 -- the scan with its blocks of 4096 terms evaluated AHEAD of the chain: all
+ *      blocks of all cells at once, each under the binade a prefix of plain block sums predicts for it, then one addition
+ *      per block along the chain (three launches per iteration; the previous iteration's finalize step sits at the head of
+ *      the first); W = 8 -- the scan, block after block; W <= 6 -- one dependent addition after the other (csrc/em_legacy.hip).
+ *        "em_serial_scan"      2 (default) as above; 3 (W = 10, 12) the first two launches of an iteration as ONE kernel that
+ *                              keeps a span's weights in LDS (half the table traffic at W = 12; measured no faster).
+ *        "em_overlap"          W >= 10: streams the batches of PWMs take turns on, 1..4 (default 2; the
  *                              context's own stream waits for the others before the call returns or copies).
  *        "em_test_skew"        (test hook) n > 0: about every n-th block gets a WRONG binade estimate -- results must not
  *                              change, only the time (the estimate never carries exactness).  0 = off.
- *        "em_table_budget_mb"  MiB of weight tables in flight (4^W floats per PWM; twice that where the scan keeps a
- *                              second copy in position 0's order: "em_serial_scan" = 1, W <= 10); the PWMs of a call go
+ *        "em_test_lookback"    (test hook, "em_serial_scan" = 3) n > 0: every n-th workgroup acts as if the look-back for
+ *                              its estimates had timed out (its blocks are then folded by their chains).  0 = off.
+ *        "em_table_budget_mb"  MiB of weight tables in flight (4^W floats per PWM; twice that where the W = 8 scan keeps a
+ *                              second copy in position 0's order); the PWMs of a call go
  *                              through in batches of that size.  0 (default) = automatic: 192 MiB for W <= 10 (what a
  *                              batch writes is still in the 256 MiB Infinity Cache when it is read), above that a
  *                              quarter of the free memory, at most 24 GiB.
@@ -267,6 +270,12 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  * h_iters / h_change (optional): iterations run and last `change` per PWM. */
 int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturation, float threshold,
              int max_iterations, const uint32_t* d_counts, const float* d_bg, int* h_iters, float* h_change);
+
+/* Test hook: the serial mode (em_fast = 2) by an EARLIER GENERATION of this library, for cross-checks against the
+ * current one (csrc/em_legacy.hip): 0 = one dependent addition after the other, 1 = the scan of csrc/seqsum.h block after
+ * block (needs W >= 8; below: as 0); 2 / 3 = back to the library's scheme ("em_serial_scan").  Every generation returns
+ * the reference's sums bit for bit; only the time differs. */
+int pengk_test_em_generation(pengk_ctx* ctx, int generation);
 
 /* Device-resident variant for benchmarking / pipelines: d_pwms n_pwm x W x 4 floats in HBM, updated in
  * place; d_state: n_pwm x 2 int32 scratch {iterations, active}; no host synchronisation. */

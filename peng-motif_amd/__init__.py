@@ -26,7 +26,7 @@ EXPORTS = [
     "pengk_memset", "pengk_warmup", "pengk_host_alloc", "pengk_host_free", "pengk_timer_create", "pengk_timer_record", "pengk_timer_elapsed_ms", "pengk_timer_destroy",
     "pengk_pack", "pengk_pack_threads", "pengk_pack_append", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
     "pengk_count", "pengk_count_bg", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
-    "pengk_seed_candidates", "pengk_iupac_aggregate", "pengk_em", "pengk_em_device", "pengk_sequential_sum_f32", "pengk_motif_similarity", "pengk_selftest_division",
+    "pengk_seed_candidates", "pengk_iupac_aggregate", "pengk_em", "pengk_em_device", "pengk_test_em_generation", "pengk_sequential_sum_f32", "pengk_motif_similarity", "pengk_selftest_division",
     "pengk_comm_unique_id", "pengk_comm_init", "pengk_comm_init_env", "pengk_comm_info", "pengk_comm_destroy",
     "pengk_allreduce_tables", "pengk_comm_check_bin_bound", "pengk_allgather",
     "pengk_comm_host_init_env", "pengk_comm_host_info", "pengk_comm_host_allgather", "pengk_comm_host_allreduce_u64",
@@ -101,6 +101,7 @@ def lib():
         L.pengk_iupac_aggregate.argtypes = [vp, C.c_int, C.c_int, vp, i64, vp, vp, vp, vp]
         L.pengk_em.argtypes = [vp, C.c_int, i64, vp, f32, f32, C.c_int, vp, vp, vp, vp]
         L.pengk_em_device.argtypes = [vp, C.c_int, i64, vp, f32, f32, C.c_int, vp, vp, vp, vp]
+        L.pengk_test_em_generation.argtypes = [vp, C.c_int]
         L.pengk_sequential_sum_f32.argtypes = [vp, vp, u64, u64, vp]
         L.pengk_selftest_division.argtypes = [vp, u64, C.c_uint32, vp]
         L.pengk_motif_similarity.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp]
@@ -226,6 +227,10 @@ class Context:
 
     def set_option(self, name, value):
         _check(lib().pengk_set_option(self.h, name.encode(), int(value)))
+
+    def test_em_generation(self, generation):
+        """Test hook: the serial EM by an earlier generation of the library (0 fold, 1 scan; 2 / 3 the current scheme)."""
+        _check(lib().pengk_test_em_generation(self.h, int(generation)))
 
     def info(self, name):
         v = C.c_int64()

@@ -138,14 +138,11 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_em_blocks) (void)hipFree(ctx->d_em_blocks);
   if (ctx->d_em_counters) (void)hipFree(ctx->d_em_counters);
   if (ctx->d_em_look) (void)hipFree(ctx->d_em_look);
-  if (ctx->d_em_rows) (void)hipFree(ctx->d_em_rows);
   for (int l = 0; l < 3; ++l) {
     if (ctx->em_streams[l]) (void)hipStreamDestroy(ctx->em_streams[l]);
     if (ctx->em_join[l]) (void)hipEventDestroy(ctx->em_join[l]);
   }
   if (ctx->em_fork) (void)hipEventDestroy(ctx->em_fork);
-  for (int l = 0; l < 3; ++l)
-    if (ctx->em_step[l]) (void)hipEventDestroy(ctx->em_step[l]);
   if (ctx->d_misc) (void)hipFree(ctx->d_misc);
   if (ctx->d_keys) (void)hipFree(ctx->d_keys);
   if (ctx->d_iupac_big) (void)hipFree(ctx->d_iupac_big);
@@ -181,21 +178,9 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     return PENGK_OK;
   }
   if (strcmp(name, "em_serial_scan") == 0) {
-    if (value < 0 || value > 4)
-      return fail(PENGK_ERR_ARG, "em_serial_scan must be 0 (dependent additions), 1 (scan), 2 (scan, blocks evaluated ahead), 3 (the same in two launches per iteration) or 4 (in three, the finalize step at the head of the weights kernel)");
+    if (value < 2 || value > 3)
+      return fail(PENGK_ERR_ARG, "em_serial_scan must be 2 (blocks evaluated ahead of their chain, three launches per iteration) or 3 (two: weights and block evaluation as one kernel); earlier generations: pengk_test_em_generation");
     ctx->em_serial_scan = (int)value;
-    return PENGK_OK;
-  }
-  if (strcmp(name, "em_stagger") == 0) {
-    ctx->em_stagger = value != 0;
-    return PENGK_OK;
-  }
-  if (strcmp(name, "em_rows") == 0) {
-    ctx->em_rows = value != 0;
-    return PENGK_OK;
-  }
-  if (strcmp(name, "em_block0") == 0) {
-    ctx->em_block0 = value != 0;
     return PENGK_OK;
   }
   if (strcmp(name, "em_test_lookback") == 0) {
@@ -256,9 +241,8 @@ int pengk_get_info(pengk_ctx* ctx, const char* name, int64_t* value) {
   }
   // K5 serial mode, blocks ahead of their chain: what the chains of the LAST pengk_em / pengk_em_device call met, summed
   // over all cells, PWMs and iterations (seqsum::WalkCounts; 0 for every other EM mode).  Synchronises with the stream.
-  static const char* const em_names[6] = {"em_fetched_blocks", "em_mispredicted_blocks", "em_restaged_blocks", "em_restaged_waits",
-                                          "em_row_blocks", "em_row_failed"};
-  for (int i = 0; i < 6; ++i)
+  static const char* const em_names[4] = {"em_fetched_blocks", "em_mispredicted_blocks", "em_restaged_blocks", "em_restaged_waits"};
+  for (int i = 0; i < 4; ++i)
     if (strcmp(name, em_names[i]) == 0) {
       unsigned long long v = 0;
       if (ctx->d_em_counters) {
@@ -572,6 +556,13 @@ int pengk_sequential_sum_f32(pengk_ctx* ctx, const float* d_terms, uint64_t n_ch
   if (!ctx || (!d_terms && n_chains && chain_len) || (!d_out && n_chains)) return fail(PENGK_ERR_ARG, "pengk_sequential_sum_f32: NULL argument");
   PENGK_ENTER(ctx);
   return launch_sequential_sum(ctx, d_terms, n_chains, chain_len, d_out);
+}
+
+int pengk_test_em_generation(pengk_ctx* ctx, int generation) {
+  if (!ctx) return fail(PENGK_ERR_ARG, "pengk_test_em_generation: NULL context");
+  if (generation < 0 || generation > 3) return fail(PENGK_ERR_ARG, "pengk_test_em_generation: 0 (dependent additions), 1 (scan), 2 / 3 (the library's scheme)");
+  ctx->em_serial_scan = generation;
+  return PENGK_OK;
 }
 
 int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,

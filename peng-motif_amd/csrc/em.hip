@@ -15,11 +15,7 @@
 // reference adds them serially in float32 (error up to 2.6e-4 relative at W=10);
 // here they are accumulated in fp64 through a fixed tree (thread -> wave -> block -> grid), so the
 // result is deterministic and within 1 ulp(float) of the exact sum.
-#include <algorithm>
-#include <type_traits>
-
-#include "pengk_internal.h"
-#include "seqsum.h"
+#include "em_common.h"
 
 namespace pengk {
 namespace {
@@ -52,20 +48,6 @@ struct WgTrace {
 #define PENGK_WG_TRACE_BEGIN(k)
 #define PENGK_WG_TRACE_END(kind, wg)
 #endif
-
-// HIMAX = 4: 256 leaves per thread (fewest partial products; best when the grid is full anyway).
-// HIMAX = 3 / 2: 64 / 16 leaves per thread, 4x / 16x more workgroups -- for small PWM batches that would
-// otherwise leave most CUs with a single wave (the 16-PWM batch of a typical run takes HIMAX = 3 at W = 10:
-// 1024 workgroups, four per CU, and a fourth of the per-workgroup reductions of HIMAX = 2).
-template <int W, int HIMAX = 4>
-struct EmGeo {
-  static constexpr int LO = 4;                               // digits taken from threadIdx (256 threads)
-  static constexpr int HI = (W - LO) < HIMAX ? (W - LO) : HIMAX;  // digits walked per thread
-  static constexpr int MID = W - LO - HI;                    // digits taken from blockIdx.x
-  static constexpr int PB = LO + MID;                        // first HI position
-  static constexpr int NB = 1 << (2 * MID);                  // blocks per PWM
-  static constexpr int CELLS = W * 4;
-};
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -329,438 +311,26 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------------------------
 // em_fast = 2, "serial": the reference's float32 arithmetic INCLUDING its summation order, bit for bit.
-// The reference adds the 4^W weights into each PWM cell one after the other in float32 (src/peng.cpp:121-127);
-// the motifs' merge and redundancy decisions downstream compare similarity scores that are exactly tied in real
-// arithmetic for reverse-complement twins, so the last bits of those sums decide what the program prints.
-// A cell's sum is inherently sequential, but cells and PWMs are independent and the weights are not:
-//   em_weights_kernel    all weights w(x) of a PWM in parallel (reference float operations), to a scratch table;
-//   em_fold_scan_kernel  (W >= 8) one wave per cell evaluates the cell's chain of roundings as a scan (seqsum.h);
-//   em_fold_kernel       (W <= 6, or option em_serial_scan = 0) one workgroup per position and PWM:
-//                        the four cells (p, a) walk THEIR terms -- the x whose digit p is a, ascending -- from LDS,
-//                        where loader waves stage them with coalesced loads, one dependent addition after the other.
-// ---------------------------------------------------------------------------------------------
-template <int W, bool T0>
-__global__ __launch_bounds__(256) void em_weights_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
-                                                         const uint32_t* __restrict__ counts, const float* __restrict__ bg,
-                                                         float saturation, float* __restrict__ wbuf,
-                                                         uint32_t* __restrict__ bad) {
-  const int pw = blockIdx.y;
-  if (state[2 * pw + 1] == 0) return;
-  __shared__ float s_pwm[W * 4];
-  if (threadIdx.x < W * 4) s_pwm[threadIdx.x] = pwms[(size_t)pw * W * 4 + threadIdx.x];
-  __syncthreads();
-  const uint32_t np = 1u << (2 * W);
-  float* out = wbuf + (size_t)pw * ((size_t)np << (T0 ? 1 : 0));
-  // A thread takes the 16 x that share their low W-2 digits: the product over those positions is built once, in the
-  // reference's order ((1*pwm[0][x0])*pwm[1][x1])... (src/peng.cpp:180-197), and the last two factors are applied per x
-  // -- the same multiplications in the same order for every x, 1.25 per x instead of W (the ten LDS look-ups and
-  // multiplications were 40 % of this kernel; the rest is its three IEEE divisions).
-  constexpr uint32_t NLOW = 1u << (2 * W - 4);
-  float hi0[4], hi1[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    hi0[a] = s_pwm[(W - 2) * 4 + a];
-    hi1[a] = s_pwm[(W - 1) * 4 + a];
-  }
-  for (uint32_t low = blockIdx.x * blockDim.x + threadIdx.x; low < NLOW; low += gridDim.x * blockDim.x) {
-    float pl = 1.0f;
-#pragma unroll
-    for (int p = 0; p < W - 2; ++p) pl = pl * s_pwm[p * 4 + ((low >> (2 * p)) & 3u)];
-#pragma unroll
-    for (uint32_t a8 = 0; a8 < 4u; ++a8) {
-      const float p8 = pl * hi0[a8];
-#pragma unroll
-      for (uint32_t a9 = 0; a9 < 4u; ++a9) {
-        const uint32_t x = low | (a8 << (2 * W - 4)) | (a9 << (2 * W - 2));
-        const float pr = p8 * hi1[a9];
-        const float odds = pr / bg[x];
-        const float v = ((float)counts[x] * saturation) / (1 + saturation / odds);  // :124-125
-        out[x] = v;
-        // position 0's cells take every fourth x: a second, permuted copy of the table with the four cells' terms
-        // contiguous (term c of cell a at np + a 4^(W-1) + c) lets the scan fetch them like the cells of position W-1
-        // (otherwise each of the four cells moves every line and issues four times the loads -- they were the last to
-        // finish)
-        if (T0) out[np + (x & 3u) * (np / 4u) + (x >> 2)] = v;
-        // a negative or non-finite weight (degenerate PWM / background entries): this PWM's cells are summed by the
-        // plain loop of the finalize kernel instead of the scan (seqsum.h)
-        if (__float_as_uint(v) > 0x7F7FFFFFu) bad[pw] = 1u;
-      }
-    }
-  }
-}
-
-// One workgroup per (position p, PWM): the four cells (p, a) of a position partition the table -- every x has exactly
-// one digit at position p -- so the workgroup streams each cell's terms, in the cell's order, through LDS:
-//   waves 1, 2  (loaders) fetch chunk s + 2 of the four term streams with coalesced 16-byte loads (a cell's terms are
-//               runs of 4^p consecutive x: whole cache lines per request instead of one line per lane and load, which
-//               held the first versions of this kernel at 3.8 and 1.9 ms per iteration), and put chunk s + 1, fetched
-//               during the previous stage, into the other LDS buffer;
-//   wave 0      (lanes 0..3 = a) adds chunk s from LDS, strictly in order: this IS the reference's rounding sequence.
-// A cell's chain is 4^(W-1) dependent float32 additions, about one per issue turn of its wave: what is left is that
-// chain (0.26 M additions at W = 10) plus one LDS read per four terms.  Cells and PWMs are independent: 10 x n_pwm
-// workgroups fill the chip from 26 PWMs on.
-template <int W>
-struct FoldGeo {
-  static constexpr uint32_t TERMS = 1u << (2 * W - 2);             // per cell
-  static constexpr uint32_t C = TERMS < 1024u ? TERMS : 1024u;     // terms per cell and stage
-  static constexpr uint32_t STAGES = TERMS / C;
-  static constexpr uint32_t QUADS = C;                             // 16-byte pieces per stage: 4 cells x C / 4
-  static constexpr uint32_t LOADERS = 128;
-  static constexpr uint32_t QPT = (QUADS + LOADERS - 1) / LOADERS;  // quads per loader thread and stage
-  static constexpr uint32_t ROW = C + 68;                          // floats per cell row in LDS: + 16 quads the adder may read past the
-                                                                   // end (never added), + 16 B (rows on different banks)
-};
-
-template <int W>
-__global__ __launch_bounds__(192) void em_fold_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
-                                                      double* __restrict__ partials, uint32_t pwm_stride) {
-  using F = FoldGeo<W>;
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const int pw = blockIdx.y;
-  if (state[2 * pw + 1] == 0) return;
-  const uint32_t p = blockIdx.x;  // position
-  const uint32_t np = 1u << (2 * W);
-  const float* w = wbuf + (size_t)pw * pwm_stride;
-  __shared__ __attribute__((aligned(16))) float buf[2][4][F::ROW];
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const uint32_t run = 1u << (2 * p);  // a cell's terms come in runs of 4^p consecutive x, one run per 4^(p+1)
-
-  // loader thread: quad q of a stage = terms 4 (q % (C/4)) .. + 3 of cell a = q / (C/4)
-  f4 pend[F::QPT];
-  const uint32_t lt = threadIdx.x - 64u;  // loader index (waves 1, 2)
-  auto fetch = [&](uint32_t stage) {
-#pragma unroll
-    for (uint32_t i = 0; i < F::QPT; ++i) {
-      const uint32_t q = lt + i * F::LOADERS;
-      if (q < F::QUADS) {
-        if (p == 0) {  // position 0: term t of cell a is x = 4 t + a -- quad q holds term q of all four cells
-          pend[i] = *reinterpret_cast<const f4*>(w + 4u * (stage * F::C + q));
-        } else {
-          const uint32_t a = q / (F::C / 4u), t = stage * F::C + 4u * (q % (F::C / 4u));
-          const uint32_t x = ((t >> (2 * p)) << (2 * p + 2)) | (a << (2 * p)) | (t & (run - 1u));
-          pend[i] = *reinterpret_cast<const f4*>(w + x);
-        }
-      }
-    }
-  };
-  auto deposit = [&](uint32_t b) {
-#pragma unroll
-    for (uint32_t i = 0; i < F::QPT; ++i) {
-      const uint32_t q = lt + i * F::LOADERS;
-      if (q < F::QUADS) {
-        if (p == 0) {
-          buf[b][0][q] = pend[i].x;
-          buf[b][1][q] = pend[i].y;
-          buf[b][2][q] = pend[i].z;
-          buf[b][3][q] = pend[i].w;
-        } else {
-          const uint32_t a = q / (F::C / 4u), j = 4u * (q % (F::C / 4u));
-          *reinterpret_cast<f4*>(&buf[b][a][j]) = pend[i];
-        }
-      }
-    }
-  };
-
-  if (wave != 0) {
-    fetch(0);
-    deposit(0);
-    if (F::STAGES > 1) fetch(1);
-  }
-  __syncthreads();
-  float acc = 0.0f;
-#pragma unroll 1
-  for (uint32_t s = 0; s < F::STAGES; ++s) {
-    if (wave != 0) {
-      if (s + 1 < F::STAGES) deposit((s + 1) & 1u);  // fetched during the previous stage
-      if (s + 2 < F::STAGES) fetch(s + 2);
-    } else if (lane < 4u) {
-      // two register sets of 16 quads: the LDS reads of the next 64 terms are in flight while these 64 are added
-      const f4* src = reinterpret_cast<const f4*>(&buf[s & 1u][lane][0]);
-      constexpr uint32_t NQ = F::C / 4u, G = NQ < 16u ? NQ : 16u;
-      static_assert(NQ % (2u * G) == 0u || NQ == G, "quads per stage");
-      f4 va[G], vb[G];
-      auto rd = [&](f4 (&v)[G], uint32_t i0) {
-#pragma unroll
-        for (uint32_t k = 0; k < G; ++k) v[k] = src[i0 + k];
-      };
-      auto add = [&](f4 (&v)[G]) {
-        // all quads of the set are "used" here at once: ONE s_waitcnt in front of the 4 G additions instead of one per
-        // quad (every instruction of the adding wave, waits included, costs the chain an issue turn)
-        if constexpr (G == 16)
-          asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-#pragma unroll
-        for (uint32_t k = 0; k < G; ++k) {
-          acc += v[k].x;
-          acc += v[k].y;
-          acc += v[k].z;
-          acc += v[k].w;
-        }
-      };
-      rd(va, 0);
-      if constexpr (NQ == G) {
-        add(va);
-      } else {
-#pragma unroll 1
-        for (uint32_t i = 0; i < NQ; i += 2u * G) {
-          // (scheduling barriers: left alone, the compiler moves each group of reads behind the additions in front
-          // of it and waits for every quad right after asking for it)
-          rd(vb, i + G);
-          __builtin_amdgcn_sched_barrier(0);
-          add(va);
-          __builtin_amdgcn_sched_barrier(0);
-          rd(va, i + 2u * G);  // unconditional (a branch here costs 32 register moves per turn): the last turn reads
-          __builtin_amdgcn_sched_barrier(0);
-          add(vb);             // the row's padding and never adds it
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (wave == 0 && lane < 4u) partials[(size_t)pw * (W * 4) + p * 4u + lane] = (double)acc;  // layout of EmGeo<W, 16>
-}
-
-// The same sums -- the same roundings, seqsum.h -- by one wave per cell: a cell's 4^(W-1) terms in blocks of 4096, each
-// block fetched with coalesced loads, spread over 64 LDS rows of 64 consecutive terms, and evaluated as 64 stretches
-// that the wave composes.  The chain is walked in 4^(W-1) / 4096 steps of ~1.4 us instead of 4^(W-1) dependent
-// additions (W = 10, 16 PWMs: 0.71 -> 0.09 ms per iteration), and a batch of PWMs fills the chip with 4 W waves per PWM.
-// What is left of a step is one wave's own dependent work: 128 additions, the prefix composition, the wait for LDS.
-template <int W>
-struct EmTerms {
-  typedef seqsum::f4 f4;
-  const float* __restrict__ w;  // the PWM's weight table (x order)
-  uint32_t p, a;                // the cell: terms are the x whose digit p >= 1 is a, ascending
-  // term c of the cell is x = [c's digits p.. | a | c's digits 0..p-1]
-  __device__ __forceinline__ uint32_t x_of(uint32_t c) const {
-    return ((c >> (2u * p)) << (2u * p + 2u)) | (a << (2u * p)) | (c & ((1u << (2u * p)) - 1u));
-  }
-  // runs of 4^p >= 4 consecutive x: 16-byte loads, terms 256 k + 4 lane .. + 3 of the block in R[4 k ..].
-  // x_of(4096 b + r) = F(b) + x_of(r) for r < 4096 (4096 b is a multiple of 4^p, or 4^p a multiple of 4096: no carry
-  // between the two parts of c): the per-lane part, sixteen byte offsets, is computed once (bind), the per-block part
-  // is a scalar -- a load costs no vector instruction (computing x_of per load was a quarter of a step).
-  uint32_t g[16];
-  __device__ __forceinline__ void bind(uint32_t lane) {
-#pragma unroll
-    for (uint32_t k = 0; k < 16u; ++k) g[k] = 4u * x_of(256u * k + 4u * lane);
-  }
-  // share `part` of NF: the loads k = part * 16 / NF .. of the block (part is wave-uniform; the selects below pick the
-  // share's offsets once per call)
-  template <uint32_t NF>
-  __device__ __forceinline__ void load(uint32_t b, uint32_t part, uint32_t lane, float (&R)[64 / NF]) const {
-    // wave-uniform (readfirstlane: the base stays in scalar registers, the load takes it plus a 32-bit lane offset)
-    const uint32_t F = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x_of(b * seqsum::BLOCK) - (a << (2u * p))));
-    const char* base = reinterpret_cast<const char*>(w + F);
-#pragma unroll
-    for (uint32_t k = 0; k < 16u / NF; ++k) {
-      uint32_t off = g[k];
-#pragma unroll
-      for (uint32_t q = 1; q < NF; ++q) off = part == q ? g[q * (16u / NF) + k] : off;
-      const f4 v = *reinterpret_cast<const f4*>(base + off);
-      R[4u * k] = v.x;
-      R[4u * k + 1u] = v.y;
-      R[4u * k + 2u] = v.z;
-      R[4u * k + 3u] = v.w;
-    }
-  }
-  template <uint32_t NF>
-  __device__ __forceinline__ void deposit(uint32_t part, uint32_t lane, const float (&R)[64 / NF], float* lds) const {
-    float* dst = lds + (4u * (16u / NF) * part + (lane >> 4)) * seqsum::SEG_STRIDE + 4u * (lane & 15u);
-#pragma unroll
-    for (uint32_t k = 0; k < 16u / NF; ++k) {
-      f4 v;
-      v.x = R[4u * k];
-      v.y = R[4u * k + 1u];
-      v.z = R[4u * k + 2u];
-      v.w = R[4u * k + 3u];
-      *reinterpret_cast<f4*>(dst + 4u * k * seqsum::SEG_STRIDE) = v;
-    }
-  }
-  __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)
-
-  // Block b straight into LDS (global_load_lds: no registers, so several blocks can be on their way and the wait for one
-  // of them is a counted s_waitcnt; seqsum.h, walk_chain).  The k-th of the sixteen loads writes 1 KiB of LDS in lane
-  // order: four rows of 64 terms, lane l the 16-byte slot l & 15 of row 4 k + (l >> 4) -- and which four terms lie there
-  // is the reader's choice: slot c of row r holds the terms 4 (c ^ (r & 15)) .. + 3 of the row, so that the lanes that
-  // read one slot number of their own rows together hit sixteen different slots (seqsum::Row::read_staged).
-  static constexpr uint32_t STAGE_LOADS = 16;
-  uint32_t gs[16];
-  __device__ __forceinline__ void bind_stage(uint32_t lane) {
-#pragma unroll
-    for (uint32_t k = 0; k < 16u; ++k) {
-      const uint32_t r = 4u * k + (lane >> 4);
-      gs[k] = 4u * x_of(64u * r + 4u * ((lane & 15u) ^ (r & 15u)));
-    }
-  }
-  __device__ __forceinline__ void stage(uint32_t b, uint32_t /*lane*/, seqsum::lds_float* buf) const {
-    const uint32_t F = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x_of(b * seqsum::BLOCK) - (a << (2u * p))));
-    const char* base = reinterpret_cast<const char*>(w + F);
-#pragma unroll
-    for (uint32_t k = 0; k < 16u; ++k)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + gs[k]),
-                                       (__attribute__((address_space(3))) void*)(buf + 256u * k), 16, 0, 0);
-  }
-};
-
-// The four cells of position 0 take every fourth float: term c of cell (0, a) is x = 4 c + a.  Two ways to feed them:
-//  * a second, permuted copy of the table that the weights kernel writes beside it (term c of cell a at
-//    np + a 4^(W-1) + c): the cells then fetch like those of position W-1.  Twice the table bytes per PWM.  W <= 10,
-//    where the tables of a batch stay in the Infinity Cache and a step costs what the evaluating wave costs;
-//  * straight from the table (EmTerms0): a block is the 16384 x from 16384 b, sixty-four dword loads per lane (lane l
-//    takes x = 4 (64 k + l) + a: each wave-load walks 1 KiB of consecutive lines and keeps a quarter of it; the four
-//    cells run side by side on one XCD and share the lines in its L2).  Four times the load instructions, and at
-//    W = 10 these four cells then finish last (0.95 -> 1.17 ms for 16 PWMs, 49 -> 56 ms for 1000); but at W = 12, where
-//    every table byte comes from HBM (128 MiB per PWM with the copy), half the bytes win: 25.1 -> 21.8 ms for 16 PWMs
-//    x 10 iterations (profiles/r03_em_experiments.log).  W >= 12.
-template <int W>
-struct ScanCopy0 {
-  static constexpr bool value = W <= 10;
-};
-template <int W>
-struct EmTerms0 {
-  const float* __restrict__ w;  // the PWM's weight table (x order)
-  uint32_t a;
-  template <uint32_t NF>
-  __device__ __forceinline__ void load(uint32_t b, uint32_t /*part*/, uint32_t lane, float (&R)[64 / NF]) const {
-    static_assert(NF == 1u, "whole blocks");
-    const float* base = w + (size_t)b * (4u * seqsum::BLOCK) + 4u * lane + a;
-#pragma unroll
-    for (uint32_t k = 0; k < 64u; ++k) R[k] = base[256u * k];
-  }
-  template <uint32_t NF>
-  __device__ __forceinline__ void deposit(uint32_t /*part*/, uint32_t lane, const float (&R)[64 / NF], float* lds) const {
-#pragma unroll
-    for (uint32_t k = 0; k < 64u; ++k) lds[k * seqsum::SEG_STRIDE + lane] = R[k];
-  }
-  __device__ __forceinline__ float serial() const { return 0.0f; }  // (unused: flagged PWMs never reach the scan)
-
-  // (as EmTerms::stage, with dword loads: the k-th of 64 writes row k, lane l the term whose place is l)
-  static constexpr uint32_t STAGE_LOADS = 64;
-  __device__ __forceinline__ void bind_stage(uint32_t) {}
-  __device__ __forceinline__ void stage(uint32_t b, uint32_t lane, seqsum::lds_float* buf) const {
-    const float* base = w + (size_t)b * (4u * seqsum::BLOCK) + a;
-#pragma unroll
-    for (uint32_t k = 0; k < 64u; ++k) {
-      const uint32_t term = ((((lane >> 2) ^ (k & 15u)) << 2) | (lane & 3u));  // slot (l >> 2) of row k holds slot ^ (k & 15)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + 4u * (64u * k + term)),
-                                       (__attribute__((address_space(3))) void*)(buf + 64u * k), 4, 0, 0);
-    }
-  }
-};
-
-// Workgroup -> (PWM, cell): consecutive workgroups go to consecutive XCDs (8 on gfx950, each with its own 4 MiB L2), so
-// the 4 W cells of a PWM are given to ONE XCD: a PWM's weight table (4^W floats, 4 MiB at W = 10) is read once per
-// position, and the cells of positions 0 .. W-3 walk it side by side within a 256 KiB window -- from that XCD's L2
-// instead of W times across the fabric (the scan is bound by those reads, not by its arithmetic).  The grid is padded to
-// whole groups of 8 PWMs; workgroups of the padding leave at once.
-template <int W>
-__global__ __launch_bounds__(seqsum::CHAIN_THREADS) void em_fold_scan_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
-                                                          double* __restrict__ partials, const uint32_t* __restrict__ bad,
-                                                          uint32_t n_pwm) {
-  static_assert((1u << (2 * W - 2)) % seqsum::BLOCK == 0u, "whole blocks per cell");
-  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
-  const uint32_t cell = slot % (4u * W), pw = (lin & 7u) + 8u * (slot / (4u * W));
-  if (pw >= n_pwm || state[2 * pw + 1] == 0 || bad[pw]) return;
-#ifndef PENGK_SCAN_LDS_PAD
-#define PENGK_SCAN_LDS_PAD 0
-#endif
-  __shared__ __attribute__((aligned(16))) float lds[seqsum::CHAIN_LDS_FLOATS + PENGK_SCAN_LDS_PAD];
-  constexpr uint32_t NP = 1u << (2 * W);
-  constexpr uint32_t NBLK = (1u << (2 * W - 2)) / seqsum::BLOCK;
-  float s;
-  if constexpr (ScanCopy0<W>::value) {
-    // position 0 reads the weights kernel's second copy, where its four cells lie like those of position W-1
-    const float* w = wbuf + (size_t)pw * 2u * NP;
-    EmTerms<W> src = (cell >> 2) == 0u ? EmTerms<W>{w + NP, (uint32_t)(W - 1), cell & 3u} : EmTerms<W>{w, cell >> 2, cell & 3u};
-    src.bind(threadIdx.x & 63u);
-    s = seqsum::fold_chain<EmTerms<W>, false>(src, NBLK, lds, threadIdx.x);
-  } else {
-    const float* w = wbuf + (size_t)pw * NP;
-    if ((cell >> 2) == 0u) {  // (block-uniform)
-      const EmTerms0<W> src0{w, cell & 3u};
-      s = seqsum::fold_chain<EmTerms0<W>, false>(src0, NBLK, lds, threadIdx.x);
-    } else {
-      EmTerms<W> src{w, cell >> 2, cell & 3u};
-      src.bind(threadIdx.x & 63u);
-      s = seqsum::fold_chain<EmTerms<W>, false>(src, NBLK, lds, threadIdx.x);
-    }
-  }
-  if (threadIdx.x == 0) partials[(size_t)pw * (W * 4) + cell] = (double)s;  // cell (p, a) = 4 p + a: layout of EmGeo<W, 16>
-}
-
-// One block per PWM: sum the per-block partials in block order, then the reference's float32
-// epilogue: normalise rows (:129), change = sum |new - old| (:132-137), swap (:140-143).
-// (The work of one PWM, by a workgroup of at least 4 W threads: em_finalize_kernel, or the last of a PWM's cells in
-// em_chain_kernel.)
-template <int W, int HIMAX>
-__device__ __forceinline__ void finalize_pwm(int pw, float* __restrict__ pwms, int32_t* __restrict__ state,
-                                             float* __restrict__ change_out, const double* __restrict__ partials, float threshold,
-                                             int max_it, uint32_t* __restrict__ bad, const float* __restrict__ wbuf, uint32_t pwm_stride,
-                                             float* s_new) {
-  using G = EmGeo<W, HIMAX>;
-  const int e = threadIdx.x;
-  // serial mode with the scan: a PWM the weights kernel flagged (a negative or non-finite weight -- degenerate inputs
-  // only) was left out by em_fold_scan_kernel; its cells are summed here, one thread per cell, by the plain loop
-  const bool flagged = bad && bad[pw];
-  if (e < G::CELLS) {
-    if (flagged) {
-      const float* w = wbuf + (size_t)pw * pwm_stride;
-      const uint32_t p = (uint32_t)e >> 2, a = (uint32_t)e & 3u;
-      float acc = 0.0f;
-      for (uint32_t c = 0; c < (1u << (2 * W - 2)); ++c)
-        acc += w[((c >> (2u * p)) << (2u * p + 2u)) | (a << (2u * p)) | (c & ((1u << (2u * p)) - 1u))];
-      s_new[e] = acc;
-    } else {
-      const double* src = partials + (size_t)pw * G::NB * G::CELLS + e;
-      double v = 0.0;
-      // (device-scope loads: in em_chain_kernel the values were written by other workgroups of the same launch)
-      for (int b = 0; b < G::NB; ++b) v += __hip_atomic_load(src + (size_t)b * G::CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_new[e] = (float)v;
-    }
-  }
-  __syncthreads();
-  if (bad && e == 0) bad[pw] = 0u;  // the next iteration's weights set it again if need be
-  if (e == 0) {
-    float* old = pwms + (size_t)pw * W * 4;
-    float change = 0.0f;
-    for (int p = 0; p < W; ++p) {
-      float sum = 0.0f;
-      for (int a = 0; a < 4; ++a) sum += s_new[p * 4 + a];
-      for (int a = 0; a < 4; ++a) s_new[p * 4 + a] /= sum;
-    }
-    for (int p = 0; p < W; ++p)
-      for (int a = 0; a < 4; ++a) {
-        change += fabsf(s_new[p * 4 + a] - old[p * 4 + a]);
-        old[p * 4 + a] = s_new[p * 4 + a];
-      }
-    const int it = state[2 * pw] + 1;
-    state[2 * pw] = it;
-    state[2 * pw + 1] = !(change <= threshold || it >= max_it);
-    change_out[pw] = change;
-  }
-}
-
-template <int W, int HIMAX>
-__global__ __launch_bounds__(64) void em_finalize_kernel(float* __restrict__ pwms, int32_t* __restrict__ state,
-                                                         float* __restrict__ change_out, const double* __restrict__ partials,
-                                                         float threshold, int max_it, uint32_t* __restrict__ bad,
-                                                         const float* __restrict__ wbuf, uint32_t pwm_stride) {
-  const int pw = blockIdx.x;
-  if (state[2 * pw + 1] == 0) return;
-  __shared__ float s_new[W * 4];
-  finalize_pwm<W, HIMAX>(pw, pwms, state, change_out, partials, threshold, max_it, bad, wbuf, pwm_stride, s_new);
-}
-
+// The reference adds the 4^W weights into each PWM cell one after the other in float32 (src/peng.cpp:121-127); the
+// motifs' merge and redundancy decisions downstream compare similarity scores that are exactly tied in real arithmetic for
+// reverse-complement twins, so the last bits of those sums decide what the program prints.  A cell's sum is inherently
+// sequential as written, but its chain of roundings has structure a wave can use (seqsum.h).
+//
 // ---- the scan with its blocks evaluated ahead of the chain (seqsum.h, "blocks ahead of their chain"; W >= 10) ----------
-// Per iteration and PWM:
-//   em_weights_span_kernel   the weights, span by span, and with them the plain sum of every block of every cell;
+// Per iteration and PWM (three launches, nothing between them but the kernel boundaries):
+//   em_weights_span_kernel   at its head the PREVIOUS iteration's finalize step -- row normalisation, change, "still
+//                            running" (fused_head: every workgroup of a PWM repeats the 4 W divisions from the cell sums
+//                            the chains stored; no arrival protocol at a chain's end, no finalize launch) --, then
+//                            the weights, span by span, and with them the plain sum of every block of every cell;
 //   (em_block_predict_kernel their prefix per cell = an estimate of the sum in front of each block; a block whose estimate
 //                            stays clear of a power of two from its first to its last term gets that binade -- for cells of
 //                            up to 1024 blocks the next kernel does that itself)
 //   em_span_eval_kernel      every block with a binade gets its two increments (block_increments) -- all blocks of all
 //                            cells at once, a workgroup per span of the table, instead of one after the other per cell;
-//   em_chain_kernel          one wave per cell walks the blocks: one addition per evaluated block, fold_block for the
-//                            others (the first block, where the sum climbs from zero, and the few where it crosses).
+//   em_chain_store_kernel    one wave per cell walks the blocks: one addition per evaluated block, fold_block for the
+//                            others (the few where the sum crosses a power of two), and stores the cell's sum;
+//   (em_serial_finish_kernel once per call: the last iteration's finalize step, every PWM's matrix into the caller's array).
+// Option em_serial_scan = 3 (W = 10, 12) runs the first two as ONE kernel, em_span_fused_kernel, below.
 // A span = 16384 consecutive x = 4^7: for a position p <= 6 a span holds block `span` of each of the four cells (p, a);
 // for p >= 7 it holds four consecutive blocks of the one cell (p, digit p of the span).
 template <int W>
@@ -1042,13 +612,10 @@ __device__ __forceinline__ bool fused_head(const FusedState& fs, uint32_t pw, ui
 // The product over the PWM columns in the reference's order ((1*pwm[0][x0])*pwm[1][x1])... (src/peng.cpp:180-197): the
 // factors of digits 0..3 once per thread, digit 4 once per 4 x, ...; the digits above the span, equal for all its x, are
 // still multiplied last, x by x -- float products do not regroup.
-// HEAD (em_serial_scan = 4): the kernel starts with the previous iteration's finalize step (fused_head: every workgroup
-// of a PWM repeats it from the cell sums the chains stored; `fs`, `k`, `threshold`, `max_it`) instead of reading the PWM
-// and its flags the last chain of the previous launch left -- the chains then need no arrival protocol.
-template <int W, bool HEAD>
-__global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __restrict__ pwms, const int32_t* __restrict__ state,
-                                                              const uint32_t* __restrict__ counts, const float* __restrict__ bg,
-                                                              float saturation, float* __restrict__ wbuf, uint32_t* __restrict__ bad,
+// The kernel starts with the previous iteration's finalize step (fused_head: `fs`, launch `k`, `threshold`, `max_it`).
+template <int W>
+__global__ __launch_bounds__(256) void em_weights_span_kernel(const uint32_t* __restrict__ counts, const float* __restrict__ bg,
+                                                              float saturation, float* __restrict__ wbuf,
                                                               float* __restrict__ sums, const uint32_t* __restrict__ bg_range,
                                                               FusedState fs, uint32_t k, float threshold, int max_it) {
   using G = BlockGeo<W>;
@@ -1058,22 +625,9 @@ __global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __res
   __shared__ float part[4][28];
   __shared__ uint32_t s_lean;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  uint32_t bg_lo = bg_range[0], bg_hi = bg_range[1];
-  if constexpr (HEAD) {
-    if (!fused_head<W>(fs, pw, k, threshold, max_it, sp == 0u, s_pwm, s_old, t)) return;
-    bad = fs.bad + (size_t)(k & 1u) * fs.bad_stride;
-  } else {
-    // (the "still running" flag, the PWM and the background's range are asked for TOGETHER -- one memory round trip in front
-    // of the span instead of three, in a kernel of ~20 us; the PWM is used before the flag is looked at for that)
-    int32_t running = state[2 * pw + 1];
-    float mine = pwms[(size_t)pw * W * 4 + (t < W * 4 ? t : 0u)];
-    // (one place where all four are needed, in front of the branch: left to itself the compiler asks for the flag, waits,
-    // branches, asks for the next ...)
-    asm volatile("" : "+s"(running), "+v"(mine), "+s"(bg_lo), "+s"(bg_hi));
-    if (t < W * 4) s_pwm[t] = mine;
-    if (running == 0) return;
-    __syncthreads();
-  }
+  const uint32_t bg_lo = bg_range[0], bg_hi = bg_range[1];
+  if (!fused_head<W>(fs, pw, k, threshold, max_it, sp == 0u, s_pwm, s_old, t)) return;
+  uint32_t* bad = fs.bad + (size_t)(k & 1u) * fs.bad_stride;
   if (t == 0) s_lean = lean_ranges_ok<W>(s_pwm, bg_lo, bg_hi, saturation) ? 1u : 0u;  // (workgroup-uniform: one PWM, one table)
   __syncthreads();
   const bool lean = s_lean != 0u;
@@ -1175,12 +729,12 @@ __global__ __launch_bounds__(256) void em_weights_span_kernel(const float* __res
 // The prefix of a cell's block sums -> block_binade of every block (cells of more than 1024 blocks; the shorter ones are
 // predicted by em_span_eval_kernel itself).  One wave per cell; a lane takes NBLK / 64 consecutive blocks.
 template <int W>
-__global__ __launch_bounds__(64) void em_block_predict_kernel(const int32_t* __restrict__ state, const uint32_t* __restrict__ bad,
+__global__ __launch_bounds__(64) void em_block_predict_kernel(const uint32_t* __restrict__ run_now, const uint32_t* __restrict__ bad,
                                                               const float* __restrict__ sums, seqsum::BlockRecord* __restrict__ rec,
                                                               uint32_t skew) {
   using G = BlockGeo<W>;
   const uint32_t pw = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
-  if (state[2 * pw + 1] == 0 || bad[pw]) return;
+  if (run_now[pw] == 0u || bad[pw]) return;
   constexpr uint32_t PER = G::NBLK / 64u;
   static_assert(G::NBLK % 64u == 0u, "whole lanes");
   const float* in = sums + ((size_t)pw * G::CELLS + cell) * G::NBLK + (size_t)lane * PER;
@@ -1267,13 +821,13 @@ __device__ __forceinline__ void span_row(const float* span, uint32_t p, uint32_t
 // the 4 W blocks that lie in it -- each block with a predicted binade gets its two increments.
 constexpr uint32_t SPAN_EVAL_WAVES = 8;
 template <int W>
-__global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(const int32_t* __restrict__ state, const float* __restrict__ wbuf,
+__global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(const uint32_t* __restrict__ run_now, const float* __restrict__ wbuf,
                                                                             seqsum::BlockRecord* __restrict__ rec,
                                                                             const uint32_t* __restrict__ bad, uint32_t n_pwm,
                                                                             const float* __restrict__ sums, uint32_t skew,
-                                                                            uint32_t extra_wgs, const uint32_t* __restrict__ run_now) {
+                                                                            uint32_t extra_wgs) {
   using G = BlockGeo<W>;
-  // (run_now: the PWMs' "still running" flags where the weights kernel keeps them itself (em_serial_scan = 4); else state[])
+  // (run_now: the PWMs' "still running" flags behind this iteration's head, FusedState::run)
   // (consecutive workgroups go to consecutive XCDs: a PWM's spans, and behind them its chains, stay on one -- as in
   // em_fold_scan_kernel; 1000 PWMs x 10 iterations: 35.5 ms, with PWM = blockIdx.y 37.5)
   PENGK_WG_TRACE_BEGIN(2);
@@ -1286,12 +840,12 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
     // BLOCK 0 of every cell: its start is known exactly (zero), and it is the
     // dearest block of a chain -- the sum climbs through some twenty binades in it, each crossing another evaluation --
     // so it is folded here, beside the evaluation of all the other blocks, instead of at the head of every chain
-    // (em_chain_kernel: 37 -> 30 us per iteration for 16 PWMs).  Four waves per workgroup (a block staged per wave in a
+    // (the chains: 37 -> 30 us per iteration for 16 PWMs).  Four waves per workgroup (a block staged per wave in a
     // quarter of the span buffer), a cell each; the record says SUM_BEHIND and carries the sum.
     const uint32_t xi = lin, xslot = xi >> 3;
     constexpr uint32_t XW = (G::CELLS + 3u) / 4u;  // workgroups per PWM
     const uint32_t pw = (xi & 7u) + 8u * (xslot / XW), cell = 4u * (xslot % XW) + wave;
-    if (pw >= n_pwm || wave >= 4u || cell >= G::CELLS || (run_now ? run_now[pw] == 0u : state[2 * pw + 1] == 0) || bad[pw]) return;
+    if (pw >= n_pwm || wave >= 4u || cell >= G::CELLS || run_now[pw] == 0u || bad[pw]) return;
     seqsum::lds_float* buf = (seqsum::lds_float*)span + wave * seqsum::BLOCK;
     const float* w = wbuf + (size_t)pw * G::NP;
     seqsum::Row mine;
@@ -1334,7 +888,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
   }
   // (the flags are looked at behind the estimates -- which touch nothing but this workgroup's LDS -- so that no branch
   // stands between the span's loads and the estimates' loads: a workgroup of a PWM that is done leaves a little later)
-  const int32_t running = run_now ? (int32_t)run_now[pw] : state[2 * pw + 1];
+  const uint32_t running = run_now[pw];
   const uint32_t flagged = bad[pw];
   constexpr uint32_t TASKS = (G::CELLS + SPAN_EVAL_WAVES - 1u) / SPAN_EVAL_WAVES;  // per wave
   seqsum::BlockRecord* cells = rec + (size_t)pw * G::CELLS * G::NBLK;
@@ -1427,73 +981,6 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
   PENGK_WG_TRACE_END(0, lin);
 }
 
-template <int W>
-__global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ state, const float* __restrict__ wbuf,
-                                                      const seqsum::BlockRecord* __restrict__ rec, double* __restrict__ partials,
-                                                      uint32_t* __restrict__ bad, uint32_t n_pwm, uint32_t* __restrict__ done,
-                                                      float* __restrict__ pwms, float* __restrict__ change_out, float threshold,
-                                                      int max_it, unsigned long long* __restrict__ counters) {
-  using G = BlockGeo<W>;
-  PENGK_WG_TRACE_BEGIN(3);
-  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
-  const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
-  if (pw >= n_pwm) return;
-  __shared__ __attribute__((aligned(16))) float lds[seqsum::WALK_LDS_FLOATS];
-  seqsum::WalkCounts wc;
-  const uint32_t lane = threadIdx.x;
-  const seqsum::BlockRecord* r = rec + ((size_t)pw * G::CELLS + cell) * G::NBLK;
-  // (the PWM's two flags and the chain's first 64 records are asked for together: one memory round trip at the head of
-  // every chain -- the kernel ends with its longest one -- instead of three)
-  int32_t running = state[2 * pw + 1];
-  uint32_t flagged = bad[pw];
-  uint4 first = reinterpret_cast<const uint4*>(r)[lane];
-  // (one place where all of them are needed, in front of the branch: left to itself the compiler asks for a flag, waits,
-  // branches, asks for the next ...)
-  asm volatile("" : "+s"(running), "+s"(flagged), "+v"(first.x), "+v"(first.y), "+v"(first.z), "+v"(first.w));
-  if (running == 0) return;
-  float s = 0.0f;
-  const float* w = wbuf + (size_t)pw * G::NP;  // (no second copy in position 0's order: few blocks are read here)
-  if (flagged) {  // (a flagged PWM: summed by finalize_pwm's plain loop)
-  } else if ((cell >> 2) == 0u) {
-    EmTerms0<W> src0{w, cell & 3u};
-    src0.bind_stage(lane);
-    s = seqsum::walk_chain(src0, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
-  } else {
-    EmTerms<W> src{w, cell >> 2, cell & 3u};
-    src.bind_stage(lane);
-    s = seqsum::walk_chain(src, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
-  }
-  // the PWM's last cell to arrive does what em_finalize_kernel does (one launch less per iteration)
-  // No fences (a device-scope release writes the XCD's whole L2 back): the sum is stored by a device-scope atomic, which
-  // is performed where all XCDs see it, the counter is bumped once that store has returned, and finalize_pwm reads the
-  // sums with device-scope loads.
-  uint32_t arrived = 0;
-  if (lane == 0) {
-    // what this chain met (pengk_get_info "em_fetched_blocks" ...): four relaxed adds per chain, nobody waits for them
-    if (wc.fetched) __hip_atomic_fetch_add(counters + 0, (unsigned long long)wc.fetched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wc.mispredicted) __hip_atomic_fetch_add(counters + 1, (unsigned long long)wc.mispredicted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wc.restaged) __hip_atomic_fetch_add(counters + 2, (unsigned long long)wc.restaged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wc.restaged_waits) __hip_atomic_fetch_add(counters + 3, (unsigned long long)wc.restaged_waits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(partials + (size_t)pw * (W * 4) + cell),
-                                (unsigned long long)__double_as_longlong((double)s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    arrived = __hip_atomic_fetch_add(&done[pw], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-  PENGK_WG_TRACE_END(wc.fetched > 255u ? 255u : wc.fetched, lin);  // (kind = blocks taken the long way)
-  if (arrived != G::CELLS - 1u) return;
-  // The one finalizing wave of a PWM: everything it reads below was written by other workgroups of THIS launch before
-  // their fetch_add on done[pw] (the exchange on `partials` returned first).  The acquire fence makes that order explicit
-  // for the compiler and the cache (one L2 invalidate per PWM, no write-back -- a release on the 4 W producers would write
-  // every XCD's L2 back and tripled the kernel).  What relies on the kernel boundary instead: the plain stores to
-  // done[pw], bad[pw], state[], pwms[] and change_out[] below are read by the NEXT launch on this stream only.
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  asm volatile("" ::: "memory");
-  if (lane == 0) done[pw] = 0u;
-  finalize_pwm<W, 16>((int)pw, pwms, state, change_out, partials, threshold, max_it, bad, wbuf, G::NP, lds);
-  PENGK_WG_TRACE_END(254, lin);  // (the PWM's last chain, with the finalize step)
-}
-
 // ---- weights, block sums, estimates and block evaluation as ONE kernel (em_serial_scan = 3; W = 10, 12) -----------------
 // An iteration of the blocks-ahead scheme above was three dependent launches -- weights (table + block sums), block
 // evaluation (the table read back, span by span), chains -- with the finalize step at the end of the last one, behind an
@@ -1517,25 +1004,17 @@ __global__ __launch_bounds__(64) void em_chain_kernel(int32_t* __restrict__ stat
 // dispatch order nor a lost workgroup can hang the launch.  Test hook em_test_lookback = n: every n-th workgroup acts as
 // if its deadline had passed.
 // per-call counters of what the chains met (pengk_get_info "em_*"): fetched, mispredicted, restaged, restaged_waits
-// (seqsum::WalkCounts), blocks passed by their row records, blocks whose row records did not hold (seqsum::Walk2Counts);
-// behind them in the same allocation: the background table's {min, max}
-constexpr int EM_COUNTERS = 6;
+// (seqsum::WalkCounts); behind them in the same allocation: the background table's {min, max}
+constexpr int EM_COUNTERS = 4;
 struct FusedGeo {
   static constexpr uint32_t THREADS = 512, WAVES = 8, CHUNK = 64;
   static constexpr unsigned long long LOOKBACK_TICKS = 50000ull;  // 500 us
-  static constexpr float ROW_MARGIN = 1.0f / 2048.0f;  // what an estimate is trusted to when it names a ROW's binade (seqsum.h, row_record)
-};
-// bytes of row records (seqsum.h, "rows ahead of their chain") a cell's blocks may leave per iteration: 2 KiB + 256 B per
-// raw row and block; a block that finds no room is folded from the table
-template <int W>
-struct RowArea {
-  static constexpr uint32_t BYTES = W <= 10 ? 64u * 1024u : 256u * 1024u;
 };
 template <int W>
 struct LookGeo {
   using G = BlockGeo<W>;
   static constexpr uint32_t CHUNKS = (G::SPANS + FusedGeo::CHUNK - 1u) / FusedGeo::CHUNK;
-  static_assert(CHUNKS <= 64u, "two levels: the earlier spans of a chunk, the earlier chunks");
+  static constexpr bool SUPPORTED = CHUNKS <= 64u;  // two levels: the earlier spans of a chunk, the earlier chunks (W = 14 would take a third)
   static constexpr size_t WORDS_PER_PWM = (size_t)(G::SPANS + CHUNKS) * G::CELLS;  // A[span][cell] | T[chunk][cell]
 };
 __device__ __forceinline__ unsigned long long look_word(uint32_t epoch, float v) {
@@ -1547,17 +1026,6 @@ __device__ __forceinline__ unsigned long long look_load(const unsigned long long
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One weight, the reference's operations (src/peng.cpp:124-125, 180-197): x = the pattern, pr over the PWM's columns in
-// position order.
-template <int W, bool LEAN>
-__device__ __forceinline__ float weight_of(const float* s_pwm, uint32_t x, uint32_t cnt, float b, float saturation) {
-  float pr = 1.0f;
-#pragma unroll
-  for (int p = 0; p < W; ++p) pr = pr * s_pwm[p * 4 + ((x >> (2 * p)) & 3u)];
-  const float odds = em_div<LEAN>(pr, b);
-  return em_div<LEAN>((float)cnt * saturation, 1 + em_div<LEAN>(saturation, odds));
-}
-
 template <int W>
 __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void em_span_fused_kernel(FusedState fs, uint32_t k, float threshold, int max_it,
                                                                           const uint32_t* __restrict__ counts,
@@ -1565,8 +1033,7 @@ __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_
                                                                           float* __restrict__ wbuf, seqsum::BlockRecord* __restrict__ rec,
                                                                           unsigned long long* __restrict__ look, uint32_t epoch,
                                                                           const uint32_t* __restrict__ bg_range, uint32_t skew,
-                                                                          uint32_t test_lookback, uint32_t extra_wgs,
-                                                                          char* __restrict__ row_area, uint32_t* __restrict__ row_cursor) {
+                                                                          uint32_t test_lookback) {
   using G = BlockGeo<W>;
   using LG = LookGeo<W>;
   constexpr uint32_t CELLS = G::CELLS, WAVES = FusedGeo::WAVES;
@@ -1584,61 +1051,7 @@ __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_
   uint32_t* bad_now = fs.bad + (size_t)(k & 1u) * fs.bad_stride;
   const uint32_t bg_lo = bg_range[0], bg_hi = bg_range[1];
 
-  if (lin < extra_wgs) {
-    // The workgroups IN FRONT of the spans': BLOCK 0 of every cell, whose start is known exactly (zero) and which is the
-    // dearest block of a chain -- the sum climbs through some twenty binades in it.  Four cells per workgroup, two waves
-    // each: the block's 4096 weights are computed here a second time (a sixth of the table's; nobody to wait for), row by
-    // row -- at step i lane l takes term 64 i + l, so that the loads of a step are as contiguous as the cell allows -- into
-    // the layout Row::read_staged reads; the even wave of the pair then folds the block from zero.
-    const uint32_t xslot = lin >> 3;
-    constexpr uint32_t XW = (CELLS + 3u) / 4u;  // workgroups per PWM
-    const uint32_t pw = (lin & 7u) + 8u * (xslot / XW), cell = 4u * (xslot % XW) + (wave >> 1);
-    if (pw >= fs.n) return;
-    if (!fused_head<W>(fs, pw, k, threshold, max_it, false, s_pwm, s_old, t)) return;
-    if (t == 0) s_lean = lean_ranges_ok<W>(s_pwm, bg_lo, bg_hi, saturation) ? 1u : 0u;
-    __syncthreads();
-    const bool lean = s_lean != 0u, live = cell < CELLS;
-    const uint32_t p = cell >> 2, a = cell & 3u;
-    float* buf = span + (wave >> 1) * seqsum::BLOCK;
-    uint32_t worst = 0u;
-    auto fill = [&](auto lean_tag) {
-      constexpr bool LEAN = decltype(lean_tag)::value;
-#pragma unroll 4
-      for (uint32_t i = 32u * (wave & 1u); i < 32u * (wave & 1u) + 32u; ++i) {
-        const uint32_t c = 64u * i + lane;  // term c of the cell: x = [c's digits p.. | a | c's digits 0..p-1]
-        const uint32_t x = ((c >> (2u * p)) << (2u * p + 2u)) | (a << (2u * p)) | (c & ((1u << (2u * p)) - 1u));
-        const float v = weight_of<W, LEAN>(s_pwm, x, counts[x], bg[x], saturation);
-        worst = max(worst, __float_as_uint(v));
-        buf[(16u * i + ((lane >> 2) ^ (i & 15u))) * 4u + (lane & 3u)] = v;  // (row i, Row::read_staged's layout)
-      }
-    };
-    if (live) {
-      if (lean) fill(std::true_type{});
-      else fill(std::false_type{});
-    }
-    if (worst > 0x7F7FFFFFu) bad_now[pw] = 1u;
-    __syncthreads();
-    if (!live || (wave & 1u)) return;
-    seqsum::Row mine;
-    mine.read_staged((const seqsum::lds_float*)buf, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    seqsum::Stats st;
-    // (a flagged PWM: its chains sum the table by the plain loop and look at no record; fold_block's loop ends whatever
-    // the terms are -- `first` grows every turn)
-    const float s0 = seqsum::fold_block(mine, lane, 0.0f, st);
-    if (lane == 0) {
-      seqsum::BlockRecord out;
-      out.e = seqsum::SUM_BEHIND;
-      out.d0 = s0;
-      out.d1 = 0.0f;
-      out.pad = 0u;
-      rec[((size_t)pw * CELLS + cell) * G::NBLK] = out;
-    }
-    PENGK_WG_TRACE_END(1, lin);
-    return;
-  }
-
-  const uint32_t sl = lin - extra_wgs, slot = sl >> 3;
+  const uint32_t sl = lin, slot = sl >> 3;
   const uint32_t pw = (sl & 7u) + 8u * (slot / G::SPANS), sp = slot % G::SPANS;
   if (pw >= fs.n) return;
   const uint32_t* cnt = counts + (size_t)sp * 16384u;
@@ -1854,7 +1267,6 @@ __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_
   for (uint32_t task = wave; task < CELLS; task += WAVES) {
     const uint32_t p = task >> 2, j = task & 3u;
     const uint32_t cell = cell_of(task), b = block_of(task);
-    if (b == 0u && extra_wgs != 0u) continue;  // (folded from zero by the workgroups in front of the spans')
     seqsum::BlockRecord* r = cells + (size_t)cell * G::NBLK + b;
     uint32_t e = seqsum::NO_BINADE;
     float before = 0.0f;
@@ -1868,67 +1280,12 @@ __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_
       }
       e = block_binade((double)before, (double)before + (double)own, skew, cell * G::NBLK + b);
     }
-    const bool by_rows = e == seqsum::NO_BINADE && est_ok && row_area != nullptr;
-    if (e == seqsum::NO_BINADE && !by_rows) {
+    if (e == seqsum::NO_BINADE) {  // (block 0, where the sum climbs from zero, and the blocks where it passes a power of two: folded by the chain)
       if (lane == 0) r->e = seqsum::NO_BINADE;
       continue;
     }
     seqsum::Row mine;
-    span_row<W>(span, p, j, lane, mine);  // (once per task, whichever way the block goes: the six ways a row lies in the span are the bulk of this loop's code)
-    if (by_rows) {
-      // No binade for the block as a whole -- block 0, where the sum climbs from zero, or a block in which it passes a
-      // power of two: its ROWS are evaluated instead, each under the binade its own estimate names and the one above, and
-      // the rows that cannot name one leave their terms behind (seqsum.h, "rows ahead of their chain").  Where to: the
-      // cell's area, by a cursor (one returning atomic per such block: ~6 per cell and iteration).
-      bool done = false;
-      {
-        const bool wrong = skew != 0u && (((cell * G::NBLK + b) * 64u + lane) * 2654435761u >> 16) % skew == 0u;
-        const seqsum::RowClass rc = seqsum::row_classify(mine, lane, before, FusedGeo::ROW_MARGIN, wrong);
-        const bool raw = !rc.certain;
-        const unsigned long long rawmask = __builtin_amdgcn_ballot_w64(raw);
-        const uint32_t n_raw = (uint32_t)__builtin_popcountll(rawmask);
-        if (n_raw <= seqsum::MAX_RAW_ROWS) {
-          const uint32_t bytes = seqsum::ROW_RECORD_BYTES + 256u * n_raw;
-          uint32_t off = 0u;
-          // (the place is asked for as soon as the size is known: the atomic's round trip lies behind the rows' evaluation)
-          if (lane == 0) off = __hip_atomic_fetch_add(row_cursor + (size_t)pw * CELLS + cell, bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          seqsum::RowRecord rr = seqsum::row_record(mine, rc);
-          off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
-          if (off + bytes <= RowArea<W>::BYTES) {
-            char* slot = row_area + ((size_t)pw * CELLS + cell) * RowArea<W>::BYTES + off;
-            const uint32_t ridx = __builtin_amdgcn_mbcnt_hi((uint32_t)(rawmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rawmask, 0u));
-            if (raw) rr.info = (rr.info & 0xFFu) | (ridx << 8);
-            uint4 ha, hb;
-            ha.x = rr.e;
-            ha.y = __float_as_uint(rr.d0);
-            ha.z = __float_as_uint(rr.d1);
-            ha.w = rr.info;
-            hb.x = __float_as_uint(rr.u0);
-            hb.y = __float_as_uint(rr.u1);
-            hb.z = 0u;
-            hb.w = 0u;
-            reinterpret_cast<uint4*>(slot)[2u * lane] = ha;
-            reinterpret_cast<uint4*>(slot)[2u * lane + 1u] = hb;
-            if (raw) {
-              seqsum::f4* dst = reinterpret_cast<seqsum::f4*>(slot + seqsum::ROW_RECORD_BYTES + 256u * ridx);
-#pragma unroll
-              for (uint32_t q = 0; q < 16u; ++q) dst[q] = mine.q[q];
-            }
-            if (lane == 0) {
-              seqsum::BlockRecord out;
-              out.e = seqsum::ROWS;
-              out.d0 = __uint_as_float(off);
-              out.d1 = __uint_as_float(n_raw);
-              out.pad = 0u;
-              *r = out;
-            }
-            done = true;
-          }
-        }
-      }
-      if (!done && lane == 0) r->e = seqsum::NO_BINADE;
-      continue;
-    }
+    span_row<W>(span, p, j, lane, mine);
     float d0, d1;
     const bool ok = seqsum::block_increments(mine, lane, seqsum::bases_of_binade(e), d0, d1);
     if (lane == 0) {
@@ -1944,24 +1301,19 @@ __global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_
 }
 
 // The chains of a launch of em_span_fused_kernel: one wave per cell; the cell's sum is stored for the next launch's head
-// (or em_fused_finish_kernel) -- a plain store, the kernel boundary orders it.
-// BY_ROWS: blocks may have left row records (seqsum.h, walk_chain_rows: one buffer for the blocks folded from the table and
-// one for the records); else walk_chain with its two block buffers.
-template <int W, bool BY_ROWS>
+// (or em_serial_finish_kernel) -- a plain store, the kernel boundary orders it.
+template <int W>
 __global__ __launch_bounds__(64) void em_chain_store_kernel(const uint32_t* __restrict__ run, const uint32_t* __restrict__ bad,
                                                             const float* __restrict__ wbuf, const seqsum::BlockRecord* __restrict__ rec,
                                                             float* __restrict__ cellsum, uint32_t n_pwm,
-                                                            unsigned long long* __restrict__ counters,
-                                                            const char* __restrict__ row_area, uint32_t* __restrict__ row_cursor) {
+                                                            unsigned long long* __restrict__ counters) {
   using G = BlockGeo<W>;
   PENGK_WG_TRACE_BEGIN(3);
   const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
   const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
   if (pw >= n_pwm) return;
-  __shared__ __attribute__((aligned(16))) float lds[BY_ROWS ? seqsum::WALK2_LDS_FLOATS : seqsum::WALK_LDS_FLOATS];
-  seqsum::Walk2Counts wc;
-  seqsum::WalkCounts wc1;
-  const char* rows = BY_ROWS ? row_area + ((size_t)pw * G::CELLS + cell) * RowArea<W>::BYTES : nullptr;
+  __shared__ __attribute__((aligned(16))) float lds[seqsum::WALK_LDS_FLOATS];
+  seqsum::WalkCounts wc;
   const uint32_t lane = threadIdx.x;
   const seqsum::BlockRecord* r = rec + ((size_t)pw * G::CELLS + cell) * G::NBLK;
   // (the PWM's two flags and the chain's first 64 records are asked for together: one memory round trip at the head of
@@ -1981,27 +1333,18 @@ __global__ __launch_bounds__(64) void em_chain_store_kernel(const uint32_t* __re
   } else if ((cell >> 2) == 0u) {
     EmTerms0<W> src0{w, cell & 3u};
     src0.bind_stage(lane);
-    if constexpr (BY_ROWS) s = seqsum::walk_chain_rows(src0, r, first, G::NBLK, rows, (seqsum::lds_float*)lds, lane, wc);
-    else s = seqsum::walk_chain(src0, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc1);
+    s = seqsum::walk_chain(src0, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
   } else {
     EmTerms<W> src{w, cell >> 2, cell & 3u};
     src.bind_stage(lane);
-    if constexpr (BY_ROWS) s = seqsum::walk_chain_rows(src, r, first, G::NBLK, rows, (seqsum::lds_float*)lds, lane, wc);
-    else s = seqsum::walk_chain(src, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc1);
-  }
-  if constexpr (!BY_ROWS) {
-    wc.fetched = wc1.fetched;
-    wc.mispredicted = wc1.mispredicted;
+    s = seqsum::walk_chain(src, r, first, G::NBLK, (seqsum::lds_float*)lds, lane, wc);
   }
   if (lane == 0) {
     cellsum[(size_t)pw * G::CELLS + cell] = s;
-    if (BY_ROWS) row_cursor[(size_t)pw * G::CELLS + cell] = 0u;  // (the next launch's blocks start over in the cell's area)
-    if (wc1.restaged) __hip_atomic_fetch_add(counters + 2, (unsigned long long)wc1.restaged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wc1.restaged_waits) __hip_atomic_fetch_add(counters + 3, (unsigned long long)wc1.restaged_waits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wc.fetched) __hip_atomic_fetch_add(counters + 0, (unsigned long long)wc.fetched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wc.mispredicted) __hip_atomic_fetch_add(counters + 1, (unsigned long long)wc.mispredicted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wc.rows) __hip_atomic_fetch_add(counters + 4, (unsigned long long)wc.rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wc.rows_failed) __hip_atomic_fetch_add(counters + 5, (unsigned long long)wc.rows_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.restaged) __hip_atomic_fetch_add(counters + 2, (unsigned long long)wc.restaged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wc.restaged_waits) __hip_atomic_fetch_add(counters + 3, (unsigned long long)wc.restaged_waits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   PENGK_WG_TRACE_END(wc.fetched > 255u ? 255u : wc.fetched, lin);
 }
@@ -2009,7 +1352,7 @@ __global__ __launch_bounds__(64) void em_chain_store_kernel(const uint32_t* __re
 // Once per call and batch, behind the last launch's chains: F_K for the PWMs that are still running (K = launches = the
 // iteration limit: they stop here), and every PWM's final matrix into the caller's array (PWM_j lives there for even j).
 template <int W>
-__global__ __launch_bounds__(64) void em_fused_finish_kernel(FusedState fs, uint32_t K, float threshold, int max_it) {
+__global__ __launch_bounds__(64) void em_serial_finish_kernel(FusedState fs, uint32_t K, float threshold, int max_it) {
   constexpr uint32_t CELLS = 4u * W;
   const uint32_t pw = blockIdx.x, t = threadIdx.x;
   __shared__ __attribute__((aligned(16))) float s_pwm[CELLS], s_old[CELLS];
@@ -2041,7 +1384,7 @@ __global__ __launch_bounds__(64) void em_fused_finish_kernel(FusedState fs, uint
 
 // What a call in this mode starts from: the caller's state as em_init_kernel leaves it, both copies of the "running"
 // flag, the "bad weight" flags, the chains' counters, the background's range for em_bg_range_kernel's min / max.
-__global__ __launch_bounds__(256) void em_fused_setup_kernel(uint32_t n, int W, float threshold, int max_it, int32_t* __restrict__ state,
+__global__ __launch_bounds__(256) void em_serial_setup_kernel(uint32_t n, int W, float threshold, int max_it, int32_t* __restrict__ state,
                                                              float* __restrict__ change, uint32_t* __restrict__ run,
                                                              unsigned long long* __restrict__ counters, uint32_t* __restrict__ bg_range,
                                                              uint32_t lean, uint32_t* __restrict__ bad, uint32_t bad_words) {
@@ -2060,16 +1403,6 @@ __global__ __launch_bounds__(256) void em_fused_setup_kernel(uint32_t n, int W, 
   change[i] = c0;
   run[i] = r;
   run[n + i] = r;
-}
-
-__global__ void em_init_kernel(int n, int W, float threshold, int max_it, int32_t* __restrict__ state,
-                               float* __restrict__ change) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float c0 = (float)W;  // `float change = pattern_length` (src/peng.cpp:101)
-  state[2 * i] = 0;
-  state[2 * i + 1] = !(c0 <= threshold || 0 >= max_it);
-  change[i] = c0;
 }
 
 template <int W, int HIMAX, bool FAST, int P>
@@ -2148,148 +1481,16 @@ namespace pengk {
 namespace {
 #endif
 
-// The serial mode with the blocks evaluated ahead of their chain (em_serial_scan = 2, W >= 10), on SEVERAL streams: the
-// PWMs go round in batches, and the batches take turns on the context's stream and up to three more.  A batch's iteration
-// is weights -> block evaluation -> chains, the first two bound by arithmetic and the last by one wave per cell waiting
-// for its next block; with several batches in flight the waits of one are filled by the others.  (Left to themselves the
-// lanes fall into step -- chains beside chains, weights beside weights: 0.83 ms for 16 PWMs x 10 iterations at W = 10
-// against 0.92 on one stream.  Holding the second lane back until the first one's first weights / evaluation / chain
-// kernel has run, so that chains run beside weights, was measured twice: no gain, behind the chains a loss --
-// profiles/r04_em_kernels.log.)
-// (PWMs are independent; every batch has its own tables, records and sums.)  `budget` = bytes of weight tables in flight.
-// What a pengk_em call in this mode starts from, in ONE launch (four to five memsets took 8-25 us apiece in front of the
-// first weights kernel): the chains' counters zero, the background's range {all ones, 0} for em_bg_range_kernel's min /
-// max -- or {0, all ones}, a range nothing accepts, with the lean division off --, every lane's flags and arrival
-// counters zero.
-__global__ __launch_bounds__(256) void em_ahead_setup_kernel(unsigned long long* __restrict__ counters, uint32_t* __restrict__ bg_range,
-                                                             uint32_t lean, char* __restrict__ partials, size_t partials_b, size_t flags_at,
-                                                             uint32_t flag_words, uint32_t lanes) {
-  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-  if (t < (uint32_t)EM_COUNTERS) counters[t] = 0ull;
-  if (t == 0) {
-    bg_range[0] = lean ? 0xFFFFFFFFu : 0u;
-    bg_range[1] = lean ? 0u : 0xFFFFFFFFu;
-  }
-  for (uint32_t l = 0; l < lanes; ++l) {
-    uint32_t* f = reinterpret_cast<uint32_t*>(partials + l * partials_b + flags_at);
-    for (uint32_t i = t; i < flag_words; i += gridDim.x * 256u) f[i] = 0u;
-  }
-}
+// The serial mode with the blocks evaluated ahead of their chain (W >= 10), on SEVERAL streams: the PWMs go round in
+// batches, and the batches take turns on the context's stream and up to three more ("lanes", option em_overlap).  A
+// batch's iteration is weights -> block evaluation -> chains (`split`), or span kernel -> chains (em_serial_scan = 3); the
+// first kernels are bound by arithmetic and the last by one wave per cell waiting for its next block: with several
+// batches in flight the waits of one are filled by the others (16 PWMs x 10 iterations at W = 10: 0.92 / 0.83 / 0.86 / 0.84 ms
+// on 1 / 2 / 3 / 4 streams in round 4; two by default).  The launches are ENQUEUED in turn as well -- iteration 1 of every
+// lane's batch, then iteration 2 ... (batch by batch, the second lane got its first kernel when the host had enqueued the
+// first lane's thirty launches: profiles/r04_em_kernels.log).  One em_serial_finish_kernel per batch.
 template <int W>
 int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
-                        const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change, size_t budget) {
-  using G = EmGeo<W, 16>;
-  using B = BlockGeo<W>;
-  const size_t np = (size_t)1 << (2 * W);
-  // lanes: option "em_overlap" (1 = one stream), as many as leave a lane at least eight PWMs (two by default: 16 PWMs x
-  // 10 iterations at W = 10 take 0.92 / 0.83 / 0.86 / 0.84 ms on 1 / 2 / 3 / 4 streams, 1000 PWMs 38.5 / 33.8 / 34.5 / 39.5 ms;
-  // four lanes of four PWMs, two lanes per half of the XCDs: 0.98 ms, also inside bench.py's step, where the host is 3 ms ahead --
-  // twice the kernels, each with its own ramp and tail, is what costs, not the enqueueing)
-  int lanes = ctx->em_overlap < 1 ? 1 : ctx->em_overlap > MAX_EM_LANES ? MAX_EM_LANES : ctx->em_overlap;
-  while (lanes > 1 && n_pwm < 8 * (int64_t)lanes) --lanes;
-  const int64_t fit = std::max<int64_t>(1, (int64_t)(budget / lanes / (np * sizeof(float))));  // tables the budget holds per lane
-  int64_t batch = fit;
-  if (batch * lanes > n_pwm) {
-    // fewer PWMs than the lanes could hold: equal shares, in whole groups of 8 PWMs (one per XCD) -- but never more
-    // tables than the budget (17 PWMs on 2 lanes with room for 9 each: 8 + 8 + 1 in three turns, not 2 x 16)
-    batch = lanes > 1 ? ((n_pwm + lanes - 1) / lanes + 7) / 8 * 8 : n_pwm;
-    if (batch > fit) batch = fit >= 8 ? fit / 8 * 8 : fit;
-  }
-  if (batch > 65528) batch = 65528;  // gridDim.y
-  // per lane: tables | cell sums, flags ("has a weight the scan cannot take"), arrival counters | block sums, records
-  const size_t tables_b = (size_t)batch * np * sizeof(float);
-  const size_t flags_at = (size_t)batch * G::CELLS * sizeof(double);
-  const size_t partials_b = (flags_at + (size_t)2 * batch * sizeof(uint32_t) + 255) / 256 * 256;
-  const size_t blocks_b = ((size_t)batch * B::CELLS * B::NBLK * (sizeof(float) + sizeof(seqsum::BlockRecord)) + 255) / 256 * 256;
-  int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, lanes * tables_b);
-  if (rc) return rc;
-  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, lanes * partials_b);
-  if (rc) return rc;
-  rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes, lanes * blocks_b);
-  if (rc) return rc;
-  if (!ctx->d_em_counters) PENGK_HIP(hipMalloc((void**)&ctx->d_em_counters, (EM_COUNTERS + 1) * sizeof(unsigned long long)));
-  // the range of the background table, for the weights kernel's choice of division (lean_ranges_ok)
-  uint32_t* bg_range = reinterpret_cast<uint32_t*>(ctx->d_em_counters + EM_COUNTERS);
-  {
-    const uint32_t flag_words = (uint32_t)(2 * batch);  // (batch <= 65528)
-    hipLaunchKernelGGL(em_ahead_setup_kernel, dim3((flag_words + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->d_em_counters, bg_range,
-                       ctx->em_lean_div ? 1u : 0u, reinterpret_cast<char*>(ctx->d_em_partials), partials_b, flags_at, flag_words,
-                       (uint32_t)lanes);
-    if (ctx->em_lean_div)
-      hipLaunchKernelGGL(em_bg_range_kernel, dim3(32), dim3(1024), 0, ctx->stream, d_bg, (uint32_t)np, bg_range);  // (np = 4^W: a multiple of 4)
-  }
-  hipStream_t streams[MAX_EM_LANES];
-  streams[0] = ctx->stream;
-  for (int l = 1; l < lanes; ++l) {
-    if (!ctx->em_streams[l - 1]) PENGK_HIP(hipStreamCreateWithFlags(&ctx->em_streams[l - 1], hipStreamNonBlocking));
-    if (!ctx->em_join[l - 1]) PENGK_HIP(hipEventCreateWithFlags(&ctx->em_join[l - 1], hipEventDisableTiming));
-    streams[l] = ctx->em_streams[l - 1];
-  }
-  if (lanes > 1 && !ctx->em_fork) PENGK_HIP(hipEventCreateWithFlags(&ctx->em_fork, hipEventDisableTiming));
-  if (lanes > 1) {  // (everything enqueued so far -- the tables' producers, em_init_kernel -- comes first on all of them)
-    PENGK_HIP(hipEventRecord(ctx->em_fork, ctx->stream));
-    for (int l = 1; l < lanes; ++l) PENGK_HIP(hipStreamWaitEvent(streams[l], ctx->em_fork, 0));
-  }
-  // Once the lanes are forked they are ALWAYS joined, also when a launch fails half way: the caller reads and frees
-  // buffers on ctx->stream, and kernels may still run on the other streams.
-  // The batches go to the lanes in turn, and the launches are ENQUEUED in turn as well: iteration 1 of every lane's batch,
-  // then iteration 2 ...  Batch by batch -- all iterations of lane 0's, then all of lane 1's -- the second lane got its
-  // first kernel only when the host had enqueued the first lane's thirty launches: with 16 PWMs the first lane was two
-  // thirds through its ten iterations by then (profiles/r04_em_kernels.log, the timeline).
-  const int rc_launch = [&]() -> int {
-    for (int64_t round0 = 0; round0 < n_pwm; round0 += batch * lanes) {
-      for (int it = 0; it < max_it; ++it) {
-        for (int l = 0; l < lanes; ++l) {
-          const int64_t first = round0 + (int64_t)l * batch;
-          if (first >= n_pwm) break;
-          const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
-          hipStream_t st = streams[l];
-          float* tables = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_tables) + l * tables_b);
-          double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->d_em_partials) + l * partials_b);
-          uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(partials) + flags_at);
-          uint32_t* done = bad + batch;
-          float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->d_em_blocks) + l * blocks_b);
-          seqsum::BlockRecord* rec = reinterpret_cast<seqsum::BlockRecord*>(sums + (size_t)batch * B::CELLS * B::NBLK);
-          hipLaunchKernelGGL((em_weights_span_kernel<W, false>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_pwms + (size_t)first * W * 4,
-                             d_state + 2 * first, d_counts, d_bg, saturation, tables, bad, sums, (const uint32_t*)bg_range, FusedState{}, 0u,
-                             0.0f, 0);
-          if (!B::PREDICT_IN_EVAL)
-            hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, d_state + 2 * first, bad, sums, rec,
-                               (uint32_t)ctx->em_test_skew);
-          const unsigned groups = (unsigned)((nb + 7) / 8 * 8);  // (PWMs in whole groups of 8, one per XCD)
-          const uint64_t extra_wgs = (uint64_t)groups * ((B::CELLS + 3) / 4);  // block 0 of every cell, in front of ...
-          const uint64_t wgs = extra_wgs + (uint64_t)groups * B::SPANS;         // ... the spans
-          const unsigned gx = 1024u;
-          hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
-                             d_state + 2 * first, (const float*)tables, rec, bad, (uint32_t)nb, (const float*)sums, (uint32_t)ctx->em_test_skew,
-                             (uint32_t)extra_wgs, (const uint32_t*)nullptr);
-          hipLaunchKernelGGL((em_chain_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, d_state + 2 * first, (const float*)tables,
-                             (const seqsum::BlockRecord*)rec, partials, bad, (uint32_t)nb, done, d_pwms + (size_t)first * W * 4,
-                             d_change + first, threshold, max_it, ctx->d_em_counters);
-        }
-      }
-      PENGK_HIP(hipGetLastError());
-    }
-    return PENGK_OK;
-  }();
-  int rc_join = PENGK_OK;
-  for (int l = 1; l < lanes; ++l) {
-    hipError_t e = hipEventRecord(ctx->em_join[l - 1], streams[l]);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->em_join[l - 1], 0);
-    if (e != hipSuccess) {
-      (void)hipStreamSynchronize(streams[l]);  // the join could not be enqueued: wait here instead
-      if (!rc_join) rc_join = hip_fail(e, "joining the EM's streams");
-    }
-  }
-  return rc_launch ? rc_launch : rc_join;
-}
-
-// The serial mode as two launches per iteration (em_serial_scan = 3; W = 10, 12): em_span_fused_kernel + em_chain_store_kernel
-// per batch of PWMs, batches taking turns on the lanes as in launch_serial_ahead, one em_fused_finish_kernel per batch.
-// `split` (em_serial_scan = 4): three launches per iteration as in launch_serial_ahead -- weights, block evaluation, chains --
-// but with the finalize step at the head of the weights kernel and chains that store their sums plainly.
-template <int W>
-int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
                         const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change, size_t budget, bool split) {
   using B = BlockGeo<W>;
   using LG = LookGeo<W>;
@@ -2307,11 +1508,9 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   const size_t tables_b = (size_t)batch * np * sizeof(float);
   const size_t sums_b = split ? ((size_t)batch * B::CELLS * B::NBLK * sizeof(float) + 255) / 256 * 256 : 0;  // (split: the plain block sums in front of the records)
   const size_t rec_b = sums_b + ((size_t)batch * B::CELLS * B::NBLK * sizeof(seqsum::BlockRecord) + 255) / 256 * 256;
-  const size_t look_b = ((size_t)batch * LG::WORDS_PER_PWM * sizeof(unsigned long long) + 255) / 256 * 256;
+  const size_t look_b = split ? 0 : ((size_t)batch * LG::WORDS_PER_PWM * sizeof(unsigned long long) + 255) / 256 * 256;
   const size_t flags_at = ((size_t)batch * B::CELLS * sizeof(float) + 255) / 256 * 256;
-  const size_t cursor_at = (flags_at + (size_t)2 * batch * sizeof(uint32_t) + 255) / 256 * 256;  // (the row records' cursors: cleared with the flags)
-  const size_t small_b = (cursor_at + (size_t)batch * B::CELLS * sizeof(uint32_t) + 255) / 256 * 256;
-  const size_t rows_b = ctx->em_rows && !split ? (size_t)batch * B::CELLS * RowArea<W>::BYTES : 0;
+  const size_t small_b = (flags_at + (size_t)2 * batch * sizeof(uint32_t) + 255) / 256 * 256;
   const size_t run_at = lanes * small_b;
   const size_t pwm1_at = (run_at + (size_t)2 * n_pwm * sizeof(uint32_t) + 255) / 256 * 256;
   int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, lanes * tables_b);
@@ -2320,11 +1519,7 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   if (rc) return rc;
   rc = ensure_scratch(ctx, &ctx->d_em_blocks, &ctx->em_blocks_bytes, lanes * rec_b);
   if (rc) return rc;
-  if (rows_b) {
-    rc = ensure_scratch(ctx, &ctx->d_em_rows, &ctx->em_rows_bytes, lanes * rows_b);
-    if (rc) return rc;
-  }
-  {
+  if (look_b) {
     // the look-back words carry the epoch of the launch that wrote them: a fresh buffer starts from zero (no launch has
     // epoch 0), and so does a counter that has gone round
     const size_t had = ctx->em_look_bytes;
@@ -2346,7 +1541,7 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
   // (the lanes' flag words lie small_b apart: the setup kernel clears everything from the first lane's flags to the last lane's)
   {
     const uint32_t words = (uint32_t)((run_at - flags_at) / sizeof(uint32_t));
-    hipLaunchKernelGGL(em_fused_setup_kernel, dim3((unsigned)((std::max<int64_t>(n_pwm, 1024) + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(em_serial_setup_kernel, dim3((unsigned)((std::max<int64_t>(n_pwm, 1024) + 255) / 256)), dim3(256), 0, ctx->stream,
                        (uint32_t)n_pwm, W, threshold, max_it, d_state, d_change, run, ctx->d_em_counters, bg_range,
                        ctx->em_lean_div ? 1u : 0u, reinterpret_cast<uint32_t*>(small + flags_at), words);
     if (ctx->em_lean_div)
@@ -2381,8 +1576,6 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
           unsigned long long* look = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->d_em_look) + l * look_b);
           float* cellsum = reinterpret_cast<float*>(small + l * small_b);
           uint32_t* bad = reinterpret_cast<uint32_t*>(small + l * small_b + flags_at);
-          uint32_t* cursor = reinterpret_cast<uint32_t*>(small + l * small_b + cursor_at);
-          char* rows = rows_b ? reinterpret_cast<char*>(ctx->d_em_rows) + l * rows_b : nullptr;
           FusedState fs;
           fs.run = run + first;
           fs.pwm0 = d_pwms + (size_t)first * W * 4;
@@ -2395,7 +1588,7 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
           fs.run_stride = (uint32_t)n_pwm;
           fs.bad_stride = (uint32_t)batch;
           if (it > max_it) {
-            hipLaunchKernelGGL((em_fused_finish_kernel<W>), dim3((unsigned)nb), dim3(64), 0, st, fs, (uint32_t)max_it, threshold, max_it);
+            hipLaunchKernelGGL((em_serial_finish_kernel<W>), dim3((unsigned)nb), dim3(64), 0, st, fs, (uint32_t)max_it, threshold, max_it);
             continue;
           }
           const uint32_t k = (uint32_t)it;
@@ -2403,43 +1596,29 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
           const uint32_t* run_now = run + (size_t)((k - 1u) & 1u) * n_pwm + first;  // behind this launch's head
           const uint32_t* bad_now = bad + (size_t)(k & 1u) * batch;
           if (split) {
-            hipLaunchKernelGGL((em_weights_span_kernel<W, true>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, (const float*)nullptr,
-                               (const int32_t*)nullptr, d_counts, d_bg, saturation, tables, (uint32_t*)nullptr, sums, (const uint32_t*)bg_range, fs,
-                               k, threshold, max_it);
+            hipLaunchKernelGGL((em_weights_span_kernel<W>), dim3(B::SPANS, (unsigned)nb), dim3(256), 0, st, d_counts, d_bg, saturation, tables,
+                               sums, (const uint32_t*)bg_range, fs, k, threshold, max_it);
+            if (!B::PREDICT_IN_EVAL)
+              hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, run_now, bad_now,
+                                 (const float*)sums, rec, (uint32_t)ctx->em_test_skew);
             const uint64_t xwgs = (uint64_t)groups * ((B::CELLS + 3) / 4), swgs = xwgs + (uint64_t)groups * B::SPANS;
             hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(1024u, (unsigned)((swgs + 1023u) / 1024u)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
-                               (const int32_t*)nullptr, (const float*)tables, rec, bad_now, (uint32_t)nb, (const float*)sums,
-                               (uint32_t)ctx->em_test_skew, (uint32_t)xwgs, run_now);
-            hipLaunchKernelGGL((em_chain_store_kernel<W, false>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
-                               (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters,
-                               (const char*)nullptr, cursor);
+                               run_now, (const float*)tables, rec, bad_now, (uint32_t)nb, (const float*)sums,
+                               (uint32_t)ctx->em_test_skew, (uint32_t)xwgs);
+            hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
+                               (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters);
             continue;
           }
-          // block 0 of every cell: by workgroups in front of the spans' (option em_block0 = 1), or left to its chain
-          const uint64_t extra_wgs = ctx->em_block0 ? (uint64_t)groups * ((B::CELLS + 3) / 4) : 0;
-          const uint64_t wgs = extra_wgs + (uint64_t)groups * B::SPANS;
-          const unsigned gx = 1024u;
-          const uint32_t epoch = ++ctx->em_epoch;
-          // The lanes out of step: lane l's first span kernel waits for lane l - 1's -- started together, the lanes run their
-          // span kernels side by side (each at half the chip) and then their chains side by side; one behind the other, a
-          // lane's chains -- waves that wait for memory -- run beside the other lane's arithmetic (option em_stagger).
-          if (ctx->em_stagger && it == 1 && round0 == 0 && l > 0 && ctx->em_step[l - 1])
-            PENGK_HIP(hipStreamWaitEvent(st, ctx->em_step[l - 1], 0));
-          hipLaunchKernelGGL((em_span_fused_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(FusedGeo::THREADS), 0, st, fs, k,
-                             threshold, max_it, d_counts, d_bg, saturation, tables, rec, look, epoch, (const uint32_t*)bg_range,
-                             (uint32_t)ctx->em_test_skew, (uint32_t)ctx->em_test_lookback, (uint32_t)extra_wgs, rows, cursor);
-          if (ctx->em_stagger && it == 1 && round0 == 0 && l + 1 < lanes) {
-            if (!ctx->em_step[l]) PENGK_HIP(hipEventCreateWithFlags(&ctx->em_step[l], hipEventDisableTiming));
-            PENGK_HIP(hipEventRecord(ctx->em_step[l], st));
+          if constexpr (LG::SUPPORTED) {
+            const uint64_t wgs = (uint64_t)groups * B::SPANS;
+            const unsigned gx = 1024u;
+            const uint32_t epoch = ++ctx->em_epoch;
+            hipLaunchKernelGGL((em_span_fused_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(FusedGeo::THREADS), 0, st, fs, k,
+                               threshold, max_it, d_counts, d_bg, saturation, tables, rec, look, epoch, (const uint32_t*)bg_range,
+                               (uint32_t)ctx->em_test_skew, (uint32_t)ctx->em_test_lookback);
           }
-          if (rows)
-            hipLaunchKernelGGL((em_chain_store_kernel<W, true>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
-                               (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters,
-                               (const char*)rows, cursor);
-          else
-            hipLaunchKernelGGL((em_chain_store_kernel<W, false>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
-                               (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters,
-                               (const char*)rows, cursor);
+          hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
+                             (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters);
         }
       }
       PENGK_HIP(hipGetLastError());
@@ -2461,24 +1640,19 @@ int launch_serial_fused(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
 #ifndef PENGK_EM_BUDGET_GIB
 #define PENGK_EM_BUDGET_GIB 24
 #endif
+// The serial mode (em_fast = 2).  W >= 10: the blocks-ahead scheme of this file; W = 4 .. 8, and any W under the test hook
+// pengk_test_em_generation (ctx->em_serial_scan = 0 / 1), the earlier generations of em_legacy.hip.
 template <int W>
 int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
                   const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
-  using G = EmGeo<W, 16>;  // HI = W - 4, one partial block per PWM
-  static_assert(G::NB == 1, "serial mode writes one row of cells per PWM");
-  static_assert(W >= 4, "a cell has at least 16 terms");
-  hipLaunchKernelGGL(em_init_kernel, dim3((unsigned)((n_pwm + 255) / 256)), dim3(256), 0, ctx->stream, (int)n_pwm, W, threshold,
-                     max_it, d_state, d_change);
-  PENGK_HIP(hipGetLastError());
   const size_t np = (size_t)1 << (2 * W);
-  // Weight tables of one batch of PWMs (4^W floats per PWM, twice that with the scan's permuted copy: 8 MiB at W = 10,
+  // Weight tables of one batch of PWMs (4^W floats per PWM, twice that with the legacy scan's permuted copy: 8 MiB at W = 10,
   // 128 MiB at W = 12); a batch is one launch per kernel and iteration.  Option "em_table_budget_mb" (0 = automatic):
   //  * tables of up to 16 MiB per PWM (W <= 10): 192 MiB per batch, so that what the weights kernel writes is still in
-  //    the 256 MiB Infinity Cache when the scan reads it W times (1000 PWMs x 10 iterations at W = 10: 48.6 ms; with
-  //    1 GiB batches 58 ms, with all PWMs in one batch 79 ms: the scan is bound by its table reads, not by arithmetic;
-  //    profiles/r03_em_budget.log);
+  //    the 256 MiB Infinity Cache when it is read again (1000 PWMs x 10 iterations at W = 10 with the round-3 scan: 48.6 ms;
+  //    with 1 GiB batches 58 ms, with all PWMs in one batch 79 ms; profiles/r03_em_budget.log);
   //  * larger tables never fit: one batch for the whole call (a quarter of the free memory at most), i.e. one launch
-  //    per kernel and iteration -- the scan then streams 12 x 64 MiB per PWM and iteration from HBM at W = 12.
+  //    per kernel and iteration.
   size_t budget = (size_t)ctx->em_table_budget_mb << 20;
   if (budget == 0) {
     if (2 * np * sizeof(float) <= ((size_t)16 << 20)) {
@@ -2490,62 +1664,15 @@ int launch_serial(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation
         budget = std::min(std::max(budget, (free_b + ctx->em_tables_bytes) / 4), (size_t)PENGK_EM_BUDGET_GIB << 30);
     }
   }
-  constexpr bool SCAN = (1u << (2 * W - 2)) >= 4u * seqsum::BLOCK;
-  const bool scan = SCAN && ctx->em_serial_scan != 0;
-  constexpr bool COPY0 = SCAN && ScanCopy0<W>::value;
-  // blocks evaluated ahead of the chain (W >= 10): span-major weights with block sums, no second copy of the table
-  if constexpr (SCAN && W >= 10) {
-    if constexpr (W <= 12) {  // (W = 14: 16384 spans per PWM would take a third look-back level; it keeps the three launches)
-      if (scan && ctx->em_serial_scan >= 3)
-        return launch_serial_fused<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change, budget,
-                                      ctx->em_serial_scan == 4);
-    }
-    if (scan && ctx->em_serial_scan >= 2)
-      return launch_serial_ahead<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change, budget);
+  if constexpr (W >= 10) {
+    // 2 (the library's scheme): weights (with the previous iteration's finalize step at their head), block evaluation,
+    // chains; 3: weights and block evaluation as one kernel -- up to W = 12: 16384 spans per PWM would take a third look-back level
+    if (ctx->em_serial_scan >= 2)
+      return launch_serial_ahead<W>(ctx, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change, budget,
+                                    ctx->em_serial_scan != 3 || !LookGeo<W>::SUPPORTED);
   }
-  const size_t pwm_stride = (scan && COPY0) ? 2 * np : np;  // floats per PWM: the weight table (+ its copy in position 0's order)
-  int64_t batch = (int64_t)(budget / (pwm_stride * sizeof(float)));
-  if (batch < 1) batch = 1;
-  if (batch > n_pwm) batch = n_pwm;
-  if (batch > 65528) batch = 65528;  // gridDim.y, in whole groups of 8 PWMs
-  int rc = ensure_scratch(ctx, (void**)&ctx->d_em_tables, &ctx->em_tables_bytes, (size_t)batch * pwm_stride * sizeof(float));
-  if (rc) return rc;
-  // partials: one row of cells per PWM, and behind them one flag per PWM ("has a weight the scan cannot take")
-  const size_t flags_at = (size_t)batch * G::CELLS * sizeof(double);
-  rc = ensure_scratch(ctx, (void**)&ctx->d_em_partials, &ctx->em_partials_bytes, flags_at + (size_t)batch * sizeof(uint32_t));
-  if (rc) return rc;
-  uint32_t* bad = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_em_partials) + flags_at);
-  PENGK_HIP(hipMemsetAsync(bad, 0, (size_t)batch * sizeof(uint32_t), ctx->stream));
-  // cells of at least four blocks are summed by the scan (seqsum.h; flagged PWMs by the finalize kernel's plain loop),
-  // the short chains of W <= 6 by the dependent-addition fold
-  const unsigned wb = (unsigned)std::min<size_t>((np / 16 + 255) / 256, 1024);  // a thread per 16 x
-  for (int64_t first = 0; first < n_pwm; first += batch) {
-    const int64_t nb = n_pwm - first < batch ? n_pwm - first : batch;
-    for (int it = 0; it < max_it; ++it) {
-      if (scan && COPY0)
-        hipLaunchKernelGGL((em_weights_kernel<W, true>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
-                           d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
-      else
-        hipLaunchKernelGGL((em_weights_kernel<W, false>), dim3(wb, (unsigned)nb), dim3(256), 0, ctx->stream, d_pwms + (size_t)first * W * 4,
-                           d_state + 2 * first, d_counts, d_bg, saturation, ctx->d_em_tables, bad);
-      bool scanned = false;
-      if constexpr (SCAN) {
-        if (scan) {
-          hipLaunchKernelGGL((em_fold_scan_kernel<W>), dim3((unsigned)(4 * W), (unsigned)((nb + 7) / 8 * 8)), dim3(seqsum::CHAIN_THREADS), 0, ctx->stream,
-                             d_state + 2 * first, ctx->d_em_tables, ctx->d_em_partials, bad, (uint32_t)nb);
-          scanned = true;
-        }
-      }
-      if (!scanned)
-        hipLaunchKernelGGL((em_fold_kernel<W>), dim3((unsigned)W, (unsigned)nb), dim3(192), 0, ctx->stream, d_state + 2 * first,
-                           ctx->d_em_tables, ctx->d_em_partials, (uint32_t)pwm_stride);
-      hipLaunchKernelGGL((em_finalize_kernel<W, 16>), dim3((unsigned)nb), dim3(64), 0, ctx->stream,
-                         d_pwms + (size_t)first * W * 4, d_state + 2 * first, d_change + first, ctx->d_em_partials, threshold, max_it,
-                         scanned ? bad : (uint32_t*)nullptr, (const float*)ctx->d_em_tables, (uint32_t)pwm_stride);
-    }
-    PENGK_HIP(hipGetLastError());
-  }
-  return PENGK_OK;
+  return launch_em_serial_legacy(ctx, W, ctx->em_serial_scan != 0 ? 1 : 0, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg,
+                                 d_state, d_change, budget);
 }
 
 // W = 2 (16 patterns, 8 cells of 4 weights): the whole EM of a PWM in one wave -- the geometry above takes four digits of

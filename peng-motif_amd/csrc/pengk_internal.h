@@ -31,16 +31,10 @@ struct pengk_ctx {
   void* d_em_look = nullptr;     // K5 serial mode, two launches per iteration: the look-back words of the spans (em.hip)
   size_t em_look_bytes = 0;
   uint32_t em_epoch = 0;         // ... and the epoch of the last launch that wrote them
-  void* d_em_rows = nullptr;     // K5 serial mode, two launches: row records of the blocks without a binade (seqsum.h)
-  size_t em_rows_bytes = 0;
-  int em_rows = 1;               // ... 0: such blocks are folded from the table by their chain
-  int em_block0 = 0;             // K5 serial mode, two launches: block 0 of every cell folded 1 = by extra workgroups of the span kernel, 0 = by its chain
   int em_test_lookback = 0;      // test hook: every n-th workgroup of em_span_fused_kernel acts as if its look-back had timed out
   unsigned long long* d_em_counters = nullptr;  // K5 serial mode: what the chains of the last pengk_em call met (seqsum::WalkCounts)
   hipStream_t em_streams[3] = {nullptr, nullptr, nullptr};  // K5 serial mode: the streams beside `stream` that batches of PWMs take turns on
   hipEvent_t em_fork = nullptr, em_join[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t em_step[3] = {nullptr, nullptr, nullptr};  // K5 serial mode, two launches: lane l's first span kernel is done (the lanes start one behind the other)
-  int em_stagger = 1;
   void* d_misc = nullptr;  // small staging buffer
   size_t misc_bytes = 0;
   void* d_bg_partials = nullptr;  // fused K1b: per-block bins

@@ -474,246 +474,6 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
   return s;
 }
 
-// ---- rows ahead of their chain ---------------------------------------------------------------------------------------
-// A block without a binade -- block 0, where the sum climbs from zero, and the few where it passes a power of two -- cost
-// the chain a fetch of its 4096 terms and three evaluations on ONE wave (fold_block: ~4 k cycles, several times per chain,
-// one chain per wave: the chain kernel's time).  The same idea one level down moves that work to where the terms already
-// are (em.hip, em_span_fused_kernel, which holds the block in LDS): the ROWS of such a block are evaluated ahead, each lane
-// its own row of 64 terms under the binade the estimate of the sum in front of THAT ROW predicts, and under the binade
-// above it (a row record: both pairs of increments); rows whose estimate cannot name one binade -- the row where the sum
-// crosses, give or take what the estimate is worth -- also leave their 64 terms behind.  The chain then passes such a
-// block as it passes a chunk of blocks: runs of rows that share the binade of s compose in one prefix (ends_behind with
-// lanes = rows), the row where the sum really crosses is added term by term from the terms left behind, and the rows
-// behind it continue under the new binade.  As one level up, exactness never rests on an estimate: a row's increments are
-// applied only if s lies in their binade and the result stays below its end; anything else -- a row that is needed term
-// by term and left no terms, a record that is not there -- sends the chain back to the block's terms in the table.
-constexpr uint32_t ROWS = 0xFFFFFFFDu;     // BlockRecord.e: the block left row records; d0 = byte offset in the cell's area, d1 = raw rows
-constexpr uint32_t RAW_NONE = 0xFFu;
-constexpr uint32_t ROW_RECORD_BYTES = 64u * 32u;  // per block; the raw rows (256 bytes each) follow
-constexpr uint32_t MAX_RAW_ROWS = 16u;
-struct RowRecord {  // 32 bytes: one per row, two 16-byte halves
-  uint32_t e;       // the lower of the two binades (NO_BINADE: the row can only be added term by term)
-  float d0, d1;     // increments under e
-  uint32_t info;    // bit 0: the pair under e + 1 is there; bits 8..15: which raw row holds this row's terms (RAW_NONE: none)
-  float u0, u1;     // increments under e + 1
-  uint32_t pad0, pad1;
-};
-
-// Row records of the block in `mine` (row l = this lane's 64 terms); `before` = the estimate of the sum in front of the
-// block, `margin` what it is trusted to (relative).  row_classify names this lane's binades (rows that are not `certain`
-// leave their terms behind), row_record returns the lane's record (raw row index not yet set).  `wrong`: test hook -- this
-// lane's binade is named one too high.
-struct RowClass {
-  uint32_t e;      // the lower binade
-  bool two;        // the estimates stay within e and e + 1
-  bool certain;    // ... within e
-};
-__device__ __forceinline__ RowClass row_classify(const Row& mine, uint32_t lane, float before, float margin, bool wrong) {
-  const float rs = mine.run1(0.0f);  // the row's plain sum
-  float incl = rs;
-  incl += row_shr<1>(0.0f, incl);
-  incl += row_shr<2>(0.0f, incl);
-  incl += row_shr<4>(0.0f, incl);
-  incl += row_shr<8>(0.0f, incl);
-  incl += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl), 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
-  incl += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl), 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
-  const float lo = (before + (incl - rs)) * (1.0f - margin), hi = (before + incl) * (1.0f + margin);
-  const bool sane = lo >= 0.0f && hi < __uint_as_float(0x7E800000u);
-  uint32_t e = sane ? binade_of(lo) : 1u;
-  const uint32_t e_hi = sane ? binade_of(hi) : 3u;
-  if (wrong && e < 200u) e += 1u;
-  RowClass c;
-  c.e = e;
-  c.two = sane && e_hi <= e + 1u;
-  c.certain = sane && e_hi == e;
-  return c;
-}
-// (a row that is `certain` by its estimates but whose base chains reach the end of the binade leaves no terms behind: if
-// the chain gets there with s in e, its own test fails and the block is folded from the table -- rare, and exact)
-__device__ __forceinline__ RowRecord row_record(const Row& mine, const RowClass& c) {
-  const uint32_t e = c.e;
-  const bool two = c.two;
-  const Bases B1 = bases_of_binade(e), B2 = bases_of_binade(e + 1u);
-  float x0 = B1.b0, x1 = B1.b1, y0 = B2.b0, y1 = B2.b1;
-  mine.run2(x0, x1);
-  mine.run2(y0, y1);
-  const bool ok2 = bits(y0) < B2.limit && bits(y1) < B2.limit;
-  RowRecord r;
-  r.e = two ? e : NO_BINADE;
-  r.d0 = x0 - B1.b0;
-  r.d1 = x1 - B1.b1;
-  r.u0 = y0 - B2.b0;
-  r.u1 = y1 - B2.b1;
-  r.info = (two && ok2 ? 1u : 0u) | (RAW_NONE << 8);
-  r.pad0 = 0u;
-  r.pad1 = 0u;
-  return r;
-}
-
-// The chain through a block that left row records (one wave; `slot` = the block's records and raw rows in LDS, s = the sum
-// in front of the block).  Returns false -- and leaves s alone -- if the block has to be folded from its terms after all.
-__device__ __forceinline__ bool walk_rows(const lds_float* slot, uint32_t lane, float& s_io) {
-  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) u4 lds_u4;
-  const u4 ra = ((const lds_u4*)slot)[2u * lane];
-  const u4 rb = ((const lds_u4*)slot)[2u * lane + 1u];
-  const uint32_t rawidx = (ra.w >> 8) & 0xFFu;
-  const bool has2 = (ra.w & 1u) != 0u;
-  float s = s_io;
-  uint32_t j = 0;
-#pragma unroll 1
-  while (j < 64u) {
-    if (bits(s) >= INF_BITS) break;  // +inf + t = +inf
-    const uint32_t e = binade_of(s);
-    const bool use1 = ra.x == e, use2 = has2 && ra.x + 1u == e;
-    const unsigned long long same = __builtin_amdgcn_ballot_w64(use1 || use2) >> j;
-    const uint32_t len = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
-    if (len != 0u) {
-      const Bases B = bases_of_binade(e);
-      const bool in = lane >= j && lane < j + len;
-      const float d0 = __uint_as_float(use1 ? ra.y : rb.x), d1 = __uint_as_float(use1 ? ra.z : rb.y);
-      const float end = ends_behind(in ? B.b0 + d0 : B.b0, in ? B.b1 + d1 : B.b1, B, s, lane);
-      const unsigned long long flagged = __builtin_amdgcn_ballot_w64(in && bits(end) >= B.limit);
-      if (!flagged) {
-        s = lane_value(end, (int)(j + len - 1u));
-        j += len;
-        continue;
-      }
-      const uint32_t L = (uint32_t)__builtin_ctzll(flagged);
-      if (L > j) s = lane_value(end, (int)(L - 1u));
-      j = L;  // row L is where the sum leaves the binade
-    }
-    const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane((int)rawidx, (int)j);
-    if (ri == RAW_NONE) return false;
-    Row raw;  // (every lane reads the same 256 bytes: the additions are the same in all of them)
-    {
-      const lds_f4* src = (const lds_f4*)(slot + (ROW_RECORD_BYTES + 256u * ri) / 4u);
-#pragma unroll
-      for (uint32_t q = 0; q < SEG / 4u; ++q) raw.q[q] = src[q];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    s = raw.run1(s);
-    ++j;
-  }
-  s_io = s;
-  return true;
-}
-
-// The chain of a cell over evaluated blocks AND blocks with row records (one wave).  As walk_chain, but: one buffer for
-// the blocks that are folded from the table (`lds`, BLOCK floats), behind it ROW_LDS_BYTES for the row records of a chunk
-// of 64 blocks, all asked for at once when the chunk starts (ONE wait per chunk instead of one memory round trip per
-// block); a block whose records did not fit, or did not hold, is folded from the table like a block without any.
-constexpr uint32_t ROW_LDS_BYTES = 32u * 1024u;
-constexpr uint32_t WALK2_LDS_FLOATS = BLOCK + ROW_LDS_BYTES / 4u;
-struct Walk2Counts {
-  uint32_t fetched = 0, mispredicted = 0, rows = 0, rows_failed = 0;
-};
-template <class Source>
-__device__ __forceinline__ float walk_chain_rows(const Source& src, const BlockRecord* __restrict__ rec, const uint4& first_records,
-                                                 uint32_t n_blocks, const char* __restrict__ row_area, lds_float* lds, uint32_t lane,
-                                                 Walk2Counts& wc) {
-  Stats st;
-  float s = 0.0f;
-  lds_float* blockbuf = lds;
-  lds_float* rowbuf = lds + BLOCK;
-#pragma unroll 1
-  for (uint32_t base = 0; base < n_blocks; base += 64u) {
-    const uint4 r = base == 0u ? first_records : reinterpret_cast<const uint4*>(rec)[base + lane];
-    const bool has_rows = r.x == ROWS;
-    // where each block's records go in LDS: an exclusive prefix of their sizes over the lanes; what lies beyond the buffer
-    // stays in memory (its block is folded from the table)
-    const uint32_t bytes = has_rows ? ROW_RECORD_BYTES + 256u * r.z : 0u;
-    uint32_t at = bytes;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)at, d, 64);
-      if ((int)lane >= d) at += o;
-    }
-    at -= bytes;
-    const bool staged = has_rows && at + bytes <= ROW_LDS_BYTES;
-    {
-      unsigned long long todo = __builtin_amdgcn_ballot_w64(staged);
-#pragma unroll 1
-      while (todo) {
-        const int b = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)r.y, b), n = (uint32_t)__builtin_amdgcn_readlane((int)bytes, b);
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)at, b);
-        const char* g = row_area + off;
-#pragma unroll 1
-        for (uint32_t k = 0; k < n; k += 1024u)  // (sizes are multiples of 256 bytes: the last piece may be short)
-          if (k + 16u * lane < n)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k + 16u * lane),
-                                             (__attribute__((address_space(3))) void*)(rowbuf + (dst + k) / 4u), 16, 0, 0);
-      }
-    }
-    const unsigned long long open = __builtin_amdgcn_ballot_w64(r.x == NO_BINADE);
-    uint32_t inbuf = NO_BINADE;  // the block in blockbuf (or on its way)
-    if (open) {
-      inbuf = base + (uint32_t)__builtin_ctzll(open);
-      src.stage(inbuf, lane, blockbuf);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t j = 0;
-    if (base == 0u && (uint32_t)__builtin_amdgcn_readfirstlane((int)r.x) == SUM_BEHIND) {
-      s = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)r.y));
-      j = 1u;
-    }
-#pragma unroll 1
-    while (j < 64u) {
-      const uint32_t e = binade_of(s);
-      const unsigned long long same = __builtin_amdgcn_ballot_w64(r.x == e) >> j;
-      const uint32_t len = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
-      if (len != 0u && bits(s) < INF_BITS) {
-        const Bases B = bases_of_binade(e);
-        const bool in = lane >= j && lane < j + len;
-        const float end = ends_behind(in ? B.b0 + __uint_as_float(r.y) : B.b0, in ? B.b1 + __uint_as_float(r.z) : B.b1, B, s, lane);
-        const unsigned long long flagged = __builtin_amdgcn_ballot_w64(in && bits(end) >= B.limit);
-        if (!flagged) {
-          s = lane_value(end, (int)(j + len - 1u));
-          j += len;
-          continue;
-        }
-        const uint32_t L = (uint32_t)__builtin_ctzll(flagged);
-        if (L > j) s = lane_value(end, (int)(L - 1u));
-        j = L;
-      }
-      const uint32_t b = base + j;
-      const uint32_t kind = (uint32_t)__builtin_amdgcn_readlane((int)r.x, (int)j);
-      if (kind == ROWS && __builtin_amdgcn_readlane(staged ? 1 : 0, (int)j)) {
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)at, (int)j);
-        if (walk_rows(rowbuf + dst / 4u, lane, s)) {
-          ++wc.rows;
-          ++j;
-          continue;
-        }
-        ++wc.rows_failed;
-      }
-      // the block's terms from the table
-      if (inbuf != b) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a later block may be on its way into the buffer: it lands first, and is asked for again below)
-        src.stage(b, lane, blockbuf);
-        if (kind != NO_BINADE) ++wc.mispredicted;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      Row mine;
-      mine.read_staged(blockbuf, lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      {  // the next block without any record of this chunk is asked for while this one is folded
-        const unsigned long long rest = j < 63u ? open & ~((2ull << j) - 1ull) : 0ull;
-        inbuf = rest ? base + (uint32_t)__builtin_ctzll(rest) : NO_BINADE;
-        if (inbuf != NO_BINADE) src.stage(inbuf, lane, blockbuf);
-      }
-      s = fold_block(mine, lane, s, st);
-      ++wc.fetched;
-      ++j;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing may still be writing LDS when the next chunk's loads start, or the LDS is given back)
-  }
-  st.flush(lane);
-  return s;
-}
-
 // The term source of a chain, for NF fetching waves: load<NF>(b, part, lane, R) fetches share `part` of block b into
 // 64 / NF registers, deposit<NF>(part, lane, R, lds) spreads them over the LDS rows.
 //

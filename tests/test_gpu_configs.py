@@ -129,12 +129,12 @@ def test_config4_em_stress_1000_top_count_seeds_plus_table(ctx):
     # ... and the scan that evaluates those sums (csrc/seqsum.h) agrees with the dependent-addition fold on all 1000
     ctx.set_option("em_fast", 2)
     try:
-        for scan in (0, 1):  # (`ser` above came from the default, 2: blocks evaluated ahead of their chain)
-            ctx.set_option("em_serial_scan", scan)
+        for scan in (0, 1, 3):  # (`ser` above came from the default, 2: blocks evaluated ahead of their chain; 3: the same in two launches)
+            ctx.test_em_generation(scan)
             dep, it3, ch3 = ctx.em(W, pw0, counts, bg_k, 1e4, 0.0, 10)
             assert dep.tobytes() == ser.tobytes() and it3.tolist() == it2.tolist() and ch3.tobytes() == ch2.tobytes(), scan
     finally:
-        ctx.set_option("em_serial_scan", 2)
+        ctx.test_em_generation(2)
         ctx.set_option("em_fast", 1)
     # The two modes differ by the REFERENCE's own float32 summation error, which grows with the table: 262144 serial
     # float32 additions per cell over 1.9e9 counted windows leave up to ~1e-3 absolute on a PWM entry here (SURVEY.md A.7

@@ -796,26 +796,29 @@ def test_em_serial_scan_equals_the_fold_on_large_tables(ctx, W):
     out = {}
     ctx.set_option("em_fast", 2)
     try:
-        for scan in (2, 1, 0):
-            ctx.set_option("em_serial_scan", scan)
+        for scan in (3, 2, 1, 0):
+            ctx.test_em_generation(scan)
             out[scan] = ctx.em(W, pwms.copy(), counts, bg_k, 1e4, 0.0, 2)
     finally:
-        ctx.set_option("em_serial_scan", 2)
+        ctx.test_em_generation(2)
         ctx.set_option("em_fast", 1)
-    for scan in (1, 2):  # 2 = the default: blocks evaluated ahead of their chain
+    for scan in (1, 2, 3):  # 2 = the default: blocks evaluated ahead of their chain; 3 = weights and evaluation as one kernel (W = 14: as 2)
         assert out[scan][0].tobytes() == out[0][0].tobytes()
         assert out[scan][1].tolist() == out[0][1].tolist() and out[scan][2].tobytes() == out[0][2].tobytes()
     assert np.isfinite(out[1][0]).all() and not np.array_equal(out[1][0], pwms)
 
 
+@pytest.mark.parametrize("scheme", [2, 3])
 @pytest.mark.parametrize("W", [10, 12])
 @pytest.mark.parametrize("skew", [1, 2, 5])
-def test_em_serial_blocks_ahead_with_wrong_binade_estimates(ctx, W, skew):
+def test_em_serial_blocks_ahead_with_wrong_binade_estimates(ctx, W, skew, scheme):
     """The serial mode evaluates a cell's blocks ahead of the chain under the binade an ESTIMATE of the sum predicts
     (csrc/seqsum.h); exactness must never rest on it.  Test hook em_test_skew = n: about every n-th block is handed
     the binade above the right one, or a binade where none is to be had (n = 1: every block) -- the chain's checks must
     turn every one of them down and fetch the block itself.  Same bits as the dependent-addition fold, on heavy-tailed
-    counts (sums that cross many binades) and with 20 PWMs on two streams."""
+    counts (sums that cross many binades) and with 20 PWMs on two streams.  scheme 3 = the two-launch variant ("em_serial_scan"
+    = 3: csrc/em.hip, em_span_fused_kernel), whose estimates come from a bounded look-back inside the kernel: there,
+    em_test_lookback = 3 * skew also makes workgroups act as if that look-back had timed out."""
     NP = 4 ** W
     rng = np.random.default_rng(100 * W + skew)
     c = rng.lognormal(1.0, 2.5, NP).astype(np.uint32)
@@ -824,14 +827,17 @@ def test_em_serial_blocks_ahead_with_wrong_binade_estimates(ctx, W, skew):
     pwms = np.maximum(rng.dirichlet(np.full(4, 0.5), size=(20 if W == 10 else 4, W)).astype(np.float32), np.float32(1e-20))
     ctx.set_option("em_fast", 2)
     try:
-        ctx.set_option("em_serial_scan", 0)
+        ctx.test_em_generation(0)
         ref = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 3)
-        ctx.set_option("em_serial_scan", 2)
+        ctx.test_em_generation(scheme)
         ctx.set_option("em_test_skew", skew)
+        ctx.set_option("em_test_lookback", 3 * skew if scheme == 3 else 0)
         got = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 3)
         met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks", "restaged_blocks", "restaged_waits")}
     finally:
         ctx.set_option("em_test_skew", 0)
+        ctx.set_option("em_test_lookback", 0)
+        ctx.test_em_generation(2)
         ctx.set_option("em_fast", 1)
     assert got[0].tobytes() == ref[0].tobytes()
     assert got[1].tolist() == ref[1].tolist() and got[2].tobytes() == ref[2].tobytes()
@@ -883,7 +889,9 @@ def test_em_blocks_ahead_at_w12_against_the_oracle_on_tables_that_cross_many_bin
         assert got[i].tobytes() == ref.astype(np.float32).tobytes(), (kind, skew, i)
         assert np.float32(change[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
     chains = len(pwms) * 4 * W * 2
-    assert met["fetched_blocks"] >= chains, met  # at least block 0 of every chain (the sum climbs from zero there)
+    # (block 0 of a chain is folded from zero beside the block evaluation and not counted; on these tables every chain
+    # still meets blocks in which its sum passes a power of two)
+    assert met["fetched_blocks"] >= chains, met
     if kind == "ramp":
         assert met["fetched_blocks"] > 10 * chains, met  # ~30 crossings per chain
     if skew:
@@ -943,14 +951,16 @@ def test_em_serial_batches_on_several_streams(ctx, golden_dir):
     ctx.set_option("em_fast", 2)
     ctx.set_option("em_table_budget_mb", 32)
     try:
-        ctx.set_option("em_serial_scan", 0)
+        ctx.test_em_generation(0)
         thr = float(np.median(ctx.em(W, pwms, d["counts"], bg_k, 1e4, 0.0, 3)[2]))  # half of the PWMs stop after <= 3 iterations
         ref = ctx.em(W, pwms, d["counts"], bg_k, 1e4, thr, 6)
-        ctx.set_option("em_serial_scan", 2)
-        for streams in (1, 2, 3, 4):
-            ctx.set_option("em_overlap", streams)
-            out[streams] = ctx.em(W, pwms, d["counts"], bg_k, 1e4, thr, 6)
+        for scheme in (2, 3):
+            ctx.test_em_generation(scheme)
+            for streams in (1, 2, 3, 4):
+                ctx.set_option("em_overlap", streams)
+                out[(scheme, streams)] = ctx.em(W, pwms, d["counts"], bg_k, 1e4, thr, 6)
     finally:
+        ctx.test_em_generation(2)
         ctx.set_option("em_overlap", 2)
         ctx.set_option("em_table_budget_mb", 0)
         ctx.set_option("em_fast", 1)
@@ -986,10 +996,10 @@ def test_em_serial_scan_equals_the_dependent_addition_fold(ctx, golden_dir, name
     ctx.set_option("em_fast", 2)
     try:
         for scan in (2, 1, 0):
-            ctx.set_option("em_serial_scan", scan)
+            ctx.test_em_generation(scan)
             out[scan] = ctx.em(W, pwms, d["counts"], bg_k, 1e4, 0.0, 3)
     finally:
-        ctx.set_option("em_serial_scan", 2)
+        ctx.test_em_generation(2)
         ctx.set_option("em_fast", 1)
     for scan in (1, 2):
         assert out[scan][0].tobytes() == out[0][0].tobytes()

@@ -16,24 +16,22 @@ import peng_motif_amd as pk  # noqa: E402
 
 def run(ctx, W, pwms, counts, bgd, thr, its, scan, skew=0, lookback=0, streams=2, budget=0, rows=1):
     ctx.set_option("em_fast", 2)
-    ctx.set_option("em_serial_scan", scan)
+    ctx.test_em_generation(scan)
     ctx.set_option("em_test_skew", skew)
     ctx.set_option("em_test_lookback", lookback)
     ctx.set_option("em_overlap", streams)
     ctx.set_option("em_table_budget_mb", budget)
-    ctx.set_option("em_rows", rows)
     try:
         t = time.time()
         out = ctx.em(W, pwms.copy(), counts, bgd, 1e4, thr, its)
         dt = time.time() - t
-        met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks", "row_blocks", "row_failed")}
+        met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks")}
     finally:
         ctx.set_option("em_test_skew", 0)
         ctx.set_option("em_test_lookback", 0)
         ctx.set_option("em_overlap", 2)
         ctx.set_option("em_table_budget_mb", 0)
-        ctx.set_option("em_rows", 1)
-        ctx.set_option("em_serial_scan", 2)
+        ctx.test_em_generation(2)
         ctx.set_option("em_fast", 1)
     return out, dt, met
 
@@ -62,7 +60,7 @@ def main():
             ref, _, _ = run(ctx, W, pwms, counts, bgd, th, its, 0)
             for scan, skew, lb, streams, budget, rows in ((2, 0, 0, 2, 0, 1), (3, 0, 0, 2, 0, 1), (3, 0, 0, 2, 0, 0), (3, 0, 0, 1, 0, 1), (3, 2, 0, 2, 0, 1), (3, 0, 3, 2, 0, 1),
                                                    (3, 5, 7, 3, 0, 1), (3, 0, 1, 2, 0, 1), (3, 0, 0, 2, 32 if W == 10 else 256, 1), (3, 1, 0, 2, 0, 1),
-                                                   (4, 0, 0, 2, 0, 1), (4, 3, 0, 1, 0, 1), (4, 0, 0, 3, 32 if W == 10 else 256, 1)):
+                                                   (1, 0, 0, 2, 0, 1), (2, 3, 0, 1, 0, 1), (2, 0, 0, 3, 32 if W == 10 else 256, 1)):
                 got, dt, met = run(ctx, W, pwms, counts, bgd, th, its, scan, skew, lb, streams, budget, rows)
                 ok = same(got, ref)
                 bad += not ok
@@ -80,7 +78,7 @@ def main():
     pwms = rng.dirichlet(np.ones(4), size=(3, W)).astype(np.float32)
     pwms[1, 3] = (0.0, 0.5, 0.5, 0.0)
     ref, _, _ = run(ctx, W, pwms, counts, bgd, 0.0, 2, 0)
-    for scan in (3, 4):
+    for scan in (3, 2):
         got, dt, met = run(ctx, W, pwms, counts, bgd, 0.0, 2, scan)
         ok = got[0].tobytes() == ref[0].tobytes() and got[1].tolist() == ref[1].tolist()
         bad += not ok

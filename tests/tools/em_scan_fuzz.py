@@ -43,10 +43,10 @@ while time.time() < t_end:
     out = {}
     skew = int(rng.choice([0, 0, 1, 3, 17]))   # test hook: wrong binade estimates for every skew-th block (mode 2 only)
     for scan in (2, 1, 0):
-        ctx.set_option("em_serial_scan", scan)
+        ctx.test_em_generation(scan)
         ctx.set_option("em_test_skew", skew if scan == 2 else 0)
         out[scan] = ctx.em(W, pw, counts, bgd, sat, thr, it)
-    ctx.set_option("em_serial_scan", 2)
+    ctx.test_em_generation(2)
     ctx.set_option("em_test_skew", 0)
     bad_modes = [k for k in (1, 2) if not (out[k][0].tobytes() == out[0][0].tobytes() and out[k][1].tolist() == out[0][1].tolist()
                                            and out[k][2].tobytes() == out[0][2].tobytes())]
@@ -54,9 +54,9 @@ while time.time() < t_end:
         # once more, all three: which of them moves?
         again = {}
         for scan in (2, 1, 0):
-            ctx.set_option("em_serial_scan", scan)
+            ctx.test_em_generation(scan)
             again[scan] = ctx.em(W, pw, counts, bgd, sat, thr, it)
-        ctx.set_option("em_serial_scan", 2)
+        ctx.test_em_generation(2)
         print("MISMATCH seed", seed, "W", W, "kind", kind, "skew", skew, "n", n, "it", it, "thr", thr, "modes that differ from the fold:", bad_modes,
               "; repeated run equals first run per mode:", {k: again[k][0].tobytes() == out[k][0].tobytes() for k in (2, 1, 0)})
         mismatches += 1

@@ -24,7 +24,7 @@ print("W", W, "kind", kind, "n", n, "conc", conc, "sat", sat, "thr", thr, "it", 
 counts = pk.DeviceArray.from_host(ctx, c); bgd = pk.DeviceArray.from_host(ctx, bg)
 out = {}
 for tag, scan, ov in (("fold",0,2),("scan1",1,2),("ahead_1stream",2,1),("ahead_2streams",2,2),("ahead_again",2,2)):
-    ctx.set_option("em_serial_scan", scan); ctx.set_option("em_overlap", ov)
+    ctx.test_em_generation(scan); ctx.set_option("em_overlap", ov)
     out[tag] = ctx.em(W, pw, counts, bgd, sat, thr, it)
 for tag in out:
     if tag == "fold": continue
@@ -37,6 +37,6 @@ for tag in out:
         print(" pwm", i, "fold", out["fold"][0][i, d[0][1]], tag, out[tag][0][i, d[0][1]], "iters", out["fold"][1][i], out[tag][1][i])
 # one iteration only
 for tag, scan in (("fold",0),("ahead",2)):
-    ctx.set_option("em_serial_scan", scan)
+    ctx.test_em_generation(scan)
     out[tag+"1"] = ctx.em(W, pw, counts, bgd, sat, 0.0, 1)
 print("one iteration same:", out["fold1"][0].tobytes() == out["ahead1"][0].tobytes())

@@ -26,10 +26,7 @@ def main():
     ap.add_argument("--nseq", type=int, default=2_000_000)
     ap.add_argument("--fast", type=int, default=2)
     ap.add_argument("--lean", type=int, default=1, help="option em_lean_div")
-    ap.add_argument("--block0", type=int, default=-1, help="option em_block0")
-    ap.add_argument("--rows", type=int, default=-1, help="option em_rows")
-    ap.add_argument("--stagger", type=int, default=-1, help="option em_stagger")
-    ap.add_argument("--scan", type=int, default=3, help="option em_serial_scan (3 = two launches per iteration, 2 = three)")
+    ap.add_argument("--scan", type=int, default=2, help="pengk_test_em_generation (2 = the library's scheme, 3 = two launches per iteration, 1 = scan, 0 = fold)")
     a = ap.parse_args()
     W, NP = a.W, 4 ** a.W
     ctx = pk.Context(0)
@@ -52,13 +49,7 @@ def main():
     change = pk.DeviceArray.from_host(ctx, np.zeros(a.pwms, np.float32))
     ctx.set_option("em_fast", a.fast)
     ctx.set_option("em_lean_div", a.lean)
-    ctx.set_option("em_serial_scan", a.scan)
-    if a.block0 >= 0:
-        ctx.set_option("em_block0", a.block0)
-    if a.rows >= 0:
-        ctx.set_option("em_rows", a.rows)
-    if a.stagger >= 0:
-        ctx.set_option("em_stagger", a.stagger)
+    ctx.test_em_generation(a.scan)
     if a.streams:
         ctx.set_option("em_overlap", a.streams)
     t0, t1 = ctx.timer(), ctx.timer()
@@ -70,8 +61,8 @@ def main():
         ctx.record(t1)
         ms.append(ctx.elapsed_ms(t0, t1))
     ms = sorted(ms[2:])
-    met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks", "restaged_blocks", "restaged_waits", "row_blocks", "row_failed")} if a.fast == 2 else {}
-    print("scan=%d block0=%d rows=%d stagger=%d streams=%d " % (a.scan, a.block0, a.rows, a.stagger, a.streams), end="")
+    met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks", "restaged_blocks", "restaged_waits")} if a.fast == 2 else {}
+    print("scan=%d streams=%d " % (a.scan, a.streams), end="")
     print("W=%d pwms=%d iters=%d: best %.4f ms  median %.4f ms  (%.2f us per iteration)  %s" % (
         W, a.pwms, a.iters, ms[0], ms[len(ms) // 2], ms[len(ms) // 2] * 1e3 / a.iters, met), flush=True)
     import hashlib

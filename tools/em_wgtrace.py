@@ -53,7 +53,7 @@ def main():
     change = pk.DeviceArray.from_host(ctx, np.zeros(a.pwms, np.float32))
     ctx.set_option("em_fast", 2)
     ctx.set_option("em_overlap", a.streams)
-    ctx.set_option("em_serial_scan", a.scan)
+    ctx.test_em_generation(a.scan)
     t0, t1 = ctx.timer(), ctx.timer()
     MAX = 1 << 20
     buf = np.zeros(3 * MAX, np.uint64)
