@@ -75,6 +75,8 @@ def parse_args():
     ap.add_argument("--config3-steps", type=int, default=3,
                     help="timed steps of the BASELINE configs[3] leg (W=12, one 12.5M x 200 bp shard per rank, 64 MiB exchange); 0 = skip")
     ap.add_argument("--config3-nseq", type=int, default=12_500_000, help="sequences per rank in the configs[3] leg")
+    ap.add_argument("--strong", type=int, default=1,
+                    help="1: also run the line's sequence set STRONG-scaled (split over the ranks; components.config2_strong); 0: skip")
     return ap.parse_args()
 
 
@@ -123,6 +125,17 @@ def max_over_ranks(rt, x):
     return float(t.item())
 
 
+def sweep_roofline(W, sweep_ms):
+    """K2+K3 against the HBM roofline: SURVEY.md 8(d)'s 28 B per pattern at max_k = 2 -- 4 B of count read, (2 + 1) x 4 B of
+    background probabilities, expected, log-p and z written -- over the HIP-event time of pengk_pattern_stats."""
+    alg = 28 * 4 ** W
+    ach = alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms and sweep_ms > 0 else 0.0
+    return {"kernel": "stats_kernel<%d> (K2+K3: background probabilities of orders 0..2, strand aggregation, expected, log-p, z)" % W,
+            "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": None, "algorithmic_bytes_per_launch": alg, "ms": round(sweep_ms, 5),
+            "note": "28 B per pattern (SURVEY.md 8d); at W = 10 the 29 MB stay in L2 / Infinity Cache and the launch is ~20 us: launch-bound, not byte-bound"}
+
+
 def golden_row(W, nseq, L, both, world):
     """What `world` ranks holding sequences [r * nseq, (r + 1) * nseq) of the seed-1 set must produce together, derived
     from the COMPILED REFERENCE shard by shard (tests/golden/make_shard_golden.py): sha256 of the summed (mirrored) count
@@ -137,25 +150,30 @@ def golden_row(W, nseq, L, both, world):
     return None
 
 
-def run_leg(rt, W, both, L, nseq, P_total, em_iters, steps, warmup, em_fast):
+def run_leg(rt, W, both, L, nseq, P_total, em_iters, steps, warmup, em_fast, seq0=None, local_only=False, row=None):
     """One configuration through the whole step, `warmup` untimed + `steps` timed passes bracketed by barriers:
     K1(+K1b) count -> C1 exchange -> mirror, V -> K2+K3 sweep -> K5 EM on this rank's share of P_total seed PWMs.
+    This rank holds sequences [seq0, seq0 + nseq) of the seed-1 set (default: rank * nseq, the weak-scaling layout).
+    local_only: no exchange, all P_total PWMs on this rank -- what ONE rank does with the sequences it is given, run by
+    every rank on its own (the denominator of a strong-scaling figure).  row = (n_per_shard, k): the reference-derived
+    row the tables are to be compared with (default: this layout's, (nseq, world)).
     Returns the tables, HIP-event times per component, the wall time of the timed steps (max over ranks) and the checks:
-    sha256 of what the ranks hold after the exchange, compared with the reference-derived row of this (W, size, N)."""
+    sha256 of what the ranks hold after the exchange, compared with that row."""
     torch, pk, lib, C, ctx, dist = rt.torch, rt.pk, rt.lib, rt.C, rt.ctx, rt.dist
     rank, world, dev = rt.rank, rt.world, rt.dev
     NP, K = 4 ** W, 2
     leg = Runtime()
+    exchanging = rt.multi and not local_only
     # ---- resident input: this rank's shard of the global synthetic set -------------------------
     nw, ni = C.c_uint64(), C.c_uint64()
     pk._check(lib.pengk_synth_sizes(nseq, L, W, 0, C.byref(nw), C.byref(ni)))
     words = torch.empty(nw.value, dtype=torch.int64, device=dev)
     items = torch.empty(max(ni.value, 1), dtype=torch.int64, device=dev)
-    ctx.synth(1, rank * nseq, nseq, L, W, 0, words, items)
+    ctx.synth(1, rank * nseq if seq0 is None else seq0, nseq, L, W, 0, words, items)
     nwin = L - W + 1
-    if rt.rccl_ranks:
+    if exchanging and rt.rccl_ranks:
         pk._check(lib.pengk_comm_check_bin_bound(ctx.h))
-    else:
+    elif exchanging:
         rt.sharding.check_global_bin_bound(nseq * ((nwin + W - 1) // W), dist)
     counts = torch.empty(NP, dtype=torch.int32, device=dev)           # uint32 bins (bit pattern)
     scal = torch.zeros(85, dtype=torch.int64, device=dev)             # [0:84] bg counts, [84] ltot
@@ -166,7 +184,7 @@ def run_leg(rt, W, both, L, nseq, P_total, em_iters, steps, warmup, em_fast):
     z = torch.empty(NP, dtype=torch.float32, device=dev)
     # EM seeds of the step: P PWMs for the whole job, split over ranks; fixed pseudo-random seed k-mers (the EM
     # stress uses the seeds SURVEY.md 8d specifies; parity of both is the tests' job)
-    my_pwms = [i for i in range(P_total) if i % world == rank]
+    my_pwms = [i for i in range(P_total) if local_only or i % world == rank]
     n_my = len(my_pwms)
     rng = np.random.default_rng(5)
     seed_ids = rng.integers(0, NP, size=P_total)
@@ -189,6 +207,8 @@ def run_leg(rt, W, both, L, nseq, P_total, em_iters, steps, warmup, em_fast):
     acc = {k: 0.0 for k in ev}
 
     def exchange():
+        if not exchanging:
+            return
         if rt.rccl_ranks:  # the ONE exchange step (C1)
             pk._check(lib.pengk_allreduce_tables(ctx.h, W, counts.data_ptr(), scal[84:].data_ptr(), scal.data_ptr()))
         else:               # no-op at N = 1; gloo rehearsal otherwise
@@ -256,7 +276,7 @@ def run_leg(rt, W, both, L, nseq, P_total, em_iters, steps, warmup, em_fast):
     torch.cuda.synchronize()
     mine = {int(i): pwms[j].cpu().numpy().tobytes().hex() for j, i in enumerate(my_pwms)}
     allp = [mine]
-    if rt.multi:
+    if exchanging:
         allp = [None] * world
         dist.all_gather_object(allp, mine)
     merged = {}
@@ -265,9 +285,10 @@ def run_leg(rt, W, both, L, nseq, P_total, em_iters, steps, warmup, em_fast):
     h_scal = scal.cpu().numpy()
     checks = {"sha_counts": sha(counts.cpu().numpy()), "sha_z": sha(z.cpu().numpy()), "sha_bg_ltot": sha(h_scal),
               "sha_em_pwms": hashlib.sha256("".join(merged[i] for i in sorted(merged)).encode()).hexdigest()}
-    row = golden_row(W, nseq, L, both, world)
+    row_n, row_k = row if row is not None else (nseq, 1 if local_only else world)
+    row = golden_row(W, row_n, L, both, row_k)
     if row is None:
-        checks_ok = {"ok": None, "why": "no reference-derived row for W=%d, %d x %d bp per rank, %d rank(s) in tests/golden/shard_prefix_checksums.json" % (W, nseq, L, world)}
+        checks_ok = {"ok": None, "why": "no reference-derived row for W=%d, %d x %d bp per shard, %d shard(s) in tests/golden/shard_prefix_checksums.json" % (W, row_n, L, row_k)}
     else:
         parts = {"counts": checks["sha_counts"] == row["sha_counts_u32"], "ltot": int(h_scal[84]) == row["ltot"],
                  "bg_counters": h_scal[:84].tolist() == row["bgcounts"], "z": checks["sha_z"] == row["sha_z"]}
@@ -350,6 +371,42 @@ def pipelined_leg(rt, args, leg, W, both, steps, warmup):
                     "of batch i + 1 (second context and stream, two sets of tables); NOT the line's value, which runs one pass after the other"}
 
 
+def config2_strong_leg(rt, args, main_leg_ms, main_checks_ok):
+    """BASELINE configs[2] STRONG-scaled, the way `north_star` words its target ("... on 10M x 200 bp at W=10 on one MI355X
+    ... and >= 6x further scaling at 8 GPUs"): the SAME 10M-sequence set split N ways -- rank r holds sequences
+    [r * n / N, (r + 1) * n / N) --, the same step (count, ONE all-reduce of the 4^W counts, sweep, EM on this rank's share of
+    the PWMs).  After the exchange every rank holds the table of the whole set: `checks_ok` compares it with the k = 1 row
+    of the weak layout (the union is the same set).  `ms_1rank`: what one rank takes for the whole set, measured in this
+    run (every rank runs it on its own, no exchange; at N = 1 it is the line's own step)."""
+    W, both, L, total = args.W, args.strand == "BOTH", args.L, args.nseq
+    world, rank = rt.world, rt.rank
+    what = "the %d x %d bp set of the line's workload split over %d rank(s): sequences [r n / N, (r + 1) n / N) on rank r" % (total, L, world)
+    if not rt.multi:
+        return {"scaling": "strong", "n_gpus": 1, "ms_per_step": round(main_leg_ms, 4), "ms_1rank": round(main_leg_ms, 4), "speedup_vs_1rank": 1.0,
+                "gbp_per_s": round(total * L / (main_leg_ms * 1e-3) / 1e9, 3), "checks_ok": main_checks_ok, "workload": what,
+                "note": "one rank: this IS the line's step (nothing is split, nothing exchanged)"}
+    lo, hi = rank * total // world, (rank + 1) * total // world
+    n = args.steps
+    split = run_leg(rt, W, both, L, hi - lo, args.pwms, args.em_iters, n, args.warmup, args.em_fast, seq0=lo, row=(total, 1))
+    ms = split.dt / n * 1e3
+    comp = {k: round(split.acc[k] / n, 4) for k in ("count", "exchange", "sweep", "em")}
+    sha_split, ok_split = split.checks, split.checks_ok
+    split = None
+    rt.torch.cuda.empty_cache()
+    one = run_leg(rt, W, both, L, total, args.pwms, args.em_iters, n, args.warmup, args.em_fast, seq0=0, local_only=True, row=(total, 1))
+    ms1 = one.dt / n * 1e3
+    same = {k: sha_split[k] == one.checks[k] for k in sha_split}  # (tables, z, background counters AND the PWMs of the EM)
+    ok1 = one.checks_ok
+    one = None
+    rt.torch.cuda.empty_cache()
+    return {"scaling": "strong", "n_gpus": world, "ms_per_step": round(ms, 4), "ms_1rank": round(ms1, 4),
+            "speedup_vs_1rank": round(ms1 / ms, 3) if ms > 0 else None, "gbp_per_s": round(total * L / (ms * 1e-3) / 1e9, 3),
+            "count_ms": comp["count"], "exchange_ms": comp["exchange"], "sweep_ms": comp["sweep"], "em_ms": comp["em"],
+            "exchange_bytes": 4 * 4 ** W + 8 * 85, "checks_ok": ok_split, "checks_ok_1rank": ok1,
+            "same_bits_as_1rank": {"ok": all(same.values()), "parts": same}, "workload": what,
+            "note": "ms_1rank: every rank runs the whole set on its own (no exchange, all PWMs), the slowest counts"}
+
+
 def config3_leg(rt, args):
     """BASELINE configs[3] as `north_star` words it: 100M x 200 bp, W = 12, sequences sharded over 8 GPUs, one all-reduce
     of the 4^12 counts (64 MiB) -- here with whatever number of ranks the launcher gave: every rank holds one 12.5M-sequence
@@ -365,7 +422,9 @@ def config3_leg(rt, args):
            "n_gpus": rt.world, "steps": n, "ms_per_step": round(ms, 4), "gbp_per_s": round(nseq * L * rt.world / (ms * 1e-3) / 1e9, 3),
            "count_ms": round(leg.acc["count"] / n, 4), "exchange_ms": round(leg.acc["exchange"] / n, 4),
            "exchange_bytes": 4 * 4 ** W + 8 * 85, "sweep_ms": round(leg.acc["sweep"] / n, 4), "em_ms": round(leg.acc["em"] / n, 4),
-           "ltot_global": int(leg.scal[84].item()), "checks": leg.checks, "checks_ok": leg.checks_ok}
+           "ltot_global": int(leg.scal[84].item()), "checks": leg.checks, "checks_ok": leg.checks_ok,
+           "scaling": "weak (one 12.5M-sequence shard per rank: N = 8 IS configs[3], smaller N are its first N shards)"}
+    out["roofline_sweep"] = sweep_roofline(W, leg.acc["sweep"] / n)
     # the leg's own K1 roofline (same definition as the line's: SURVEY.md 8d algorithmic bytes / the HIP-event time of the count)
     count_ms = leg.acc["count"] / n
     alg = (nseq * L + 3) // 4 + 8 * int(leg.ni.value) + 4 * 4 ** W
@@ -643,11 +702,19 @@ def main():
 
         # ---- BASELINE configs[3]'s shard per rank (W = 12, 12.5M x 200 bp, 64 MiB exchange): its own leg, its own checks ----
         config3 = None
+        main_ms = dt / args.steps * 1e3
         if args.config3_steps > 0 and not (W == 12 and nseq == args.config3_nseq):
             leg = step = exchange = words = items = None  # (the closures hold the W = 10 tables)
             counts = scal = V = bgprob = expected = logp = z = pwms = pw_init = em_state = em_change = None
             torch.cuda.empty_cache()
             config3 = config3_leg(rt, args)
+        # ---- the line's sequence set strong-scaled: split over the ranks, one all-reduce, same step ----
+        strong = None
+        if args.strong:
+            leg = step = exchange = words = items = None
+            counts = scal = V = bgprob = expected = logp = z = pwms = pw_init = em_state = em_change = None
+            torch.cuda.empty_cache()
+            strong = config2_strong_leg(rt, args, main_ms, checks_ok)
 
     ms_per_step = dt / args.steps * 1e3
     total_bases = nseq * L * world
@@ -668,7 +735,14 @@ def main():
         out = {
             "metric": "4^W pattern z-scores/s + EM PWM-kmer evals/s at W=10; Gbp/s k-mer count",
             "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            # per-GPU work is fixed as N grows (every rank holds its own 10M-sequence shard): the legs that split a FIXED
+            # job over the ranks say so themselves (components.config2_strong, components.config4: "scaling": "strong")
+            "scaling": "weak", "vs_baseline": None,
+            # how the exchange step ran: ranks of the library's RCCL communicator (0 = no communicator: one rank, or the gloo
+            # rehearsal), and -- if the library's communicator could not be created and the ranks agreed to run the exchange
+            # as torch.distributed's all_reduce instead -- why.  A measured multi-GPU line has rccl_ranks = n_gpus and null here.
+            "rccl_ranks": rccl_ranks, "exchange_fallback": exchange_fallback,
             "dtype": "u32 counts / f32 scores / f32 serial EM sums (f64 tree sums in the throughput EM mode)", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d bp per GPU, W=%d, %s strands, bg-order 2 (%s); step = count + all-reduce + sweep + EM(%d PWMs x %d it)"
                        % (nseq, L, W, "both" if both else "plus", baseline_config_name(nseq, L, W, both), P_total, args.em_iters),
@@ -757,7 +831,20 @@ def main():
         if config3 is not None:
             out["components"]["config3"] = config3
         if config4 is not None:
+            config4["scaling"] = "strong (the same 1000 PWMs dealt to the ranks; ms_1rank_equiv is measured in the same run)"
             out["components"]["config4"] = config4
+        if strong is not None:
+            out["components"]["config2_strong"] = strong
+        out["roofline_sweep"] = sweep_roofline(W, sweep_ms)
+        if k4:
+            # K4 against the HBM roofline: SURVEY.md 8(d)'s 16 B per visited k-mer (8 B count + 4 B expected + 4 B background
+            # probability; the device keeps 32-bit counts: 12 B move) over the wall time of one pengk_iupac_aggregate call
+            # (id upload, kernels, result download, libm epilogue): a latency-bound batch, nowhere near the byte roofline
+            k4_ach = 16 * k4[1] / k4[2] / 1e9
+            out["roofline_k4"] = {"kernel": "pengk_iupac_aggregate: iupac_block_kernel / list pipeline + iupac_fold_kernel (K4), %d patterns of one hill-climb round, %d underlying k-mers" % (k4[0], k4[1]),
+                                  "bound": "hbm", "achieved": round(k4_ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k4_ach / HBM_PEAK_GBS, 6),
+                                  "traffic": None, "algorithmic_bytes_per_call": 16 * k4[1], "ms": round(k4[2] * 1e3, 4),
+                                  "note": "16 B per visited k-mer (SURVEY.md 8d) over the HOST-side wall time of the call, transfers and epilogue included; bound by the latency of a ~0.15 ms call, not by bytes"}
         # everything this process holds on the GPU goes before the host-side legs run: the end-to-end CLI below is its
         # own process on the same card, and its context start-up / exit were measured 0.2 s slower beside a parent that
         # still held 8 GB of device memory and two live contexts
@@ -790,7 +877,7 @@ def mem_available_gb():
     return 0.0
 
 
-def reference_same_box(fa, tmp, W, both, L, nseq, our_wall, cpu_base, our_best=None):
+def reference_same_box(fa, tmp, W, both, L, nseq, our_wall, cpu_base, our_best=None, our_cold=None):
     """The compiled reference CLI (oracle/_ref/peng_motif_ref, its default --threads 1) on the SAME full-size FASTA, on this
     box's host cores, in this run: the denominator north_star asks for.  Skipped -- with the reason -- when the binary did
     not travel, when the box has too little free memory (the reference keeps ~12 bytes per base) or when the
@@ -825,7 +912,8 @@ def reference_same_box(fa, tmp, W, both, L, nseq, our_wall, cpu_base, our_best=N
     if os.path.exists(ours) and os.path.exists(meme):
         same = open(ours, "rb").read() == open(meme, "rb").read()
     return {"reference_wall_s_same_box": round(wall, 2), "speedup_same_box": round(wall / our_wall, 1),
-            "speedup_policy": "ONE run of the reference (it takes ~50 s) over the MEDIAN of peng_motif's runs; the ratio to the best run is beside it",
+            "speedup_cold": round(wall / our_cold, 1) if our_cold else None,
+            "speedup_policy": "ONE run of the reference (it takes ~50 s) over the MEDIAN of peng_motif's runs (warm: the runs behind the first); the ratio to the FIRST run (speedup_cold) and to the best run are beside it",
             "speedup_same_box_vs_best_run": round(wall / our_best, 1) if our_best else None, "threads": 1,
             "host_cores": os.cpu_count(), "extrapolated_from_sample_s": round(est, 1) if est else None,
             "meme_identical_to_reference": same,
@@ -867,6 +955,10 @@ def e2e_cli(args, W, both, L, nseq):
             for _ in range(12):
                 r = subprocess.run([exe, small, "-w", "8", "-o", os.path.join(tmp, "probe.meme")], stdout=subprocess.DEVNULL,
                                    stderr=subprocess.PIPE, env=dict(os.environ, PENGK_TIMING_CREATE="1"), timeout=300)
+                if r.returncode != 0:  # (a probe that failed is an error of the leg, never a lap to be tried again)
+                    return {"error": "the device-ready probe (peng_motif on MafK_100seqs.fasta) exited %d after %d earlier probe(s): %s"
+                                     % (r.returncode, len(probe), r.stderr.decode(errors="replace")[-300:]),
+                            "device_ready_probe_first_stream_ms": probe}, None
                 lap = [float(l.rsplit(": ", 1)[1].split()[0]) for l in r.stderr.decode(errors="replace").split("\n")
                        if l.startswith("[pengk_create] stream")]
                 probe.append(lap[0] if lap else None)
@@ -910,6 +1002,11 @@ def e2e_cli(args, W, both, L, nseq):
         n_motifs = sum(1 for l in open(os.path.join(tmp, "o.meme")) if l.startswith("MOTIF"))
         is_c2 = (nseq, L, W, both) == (10_000_000, 200, 10, True)
         res = {"wall_s": round(median, 3), "wall_s_is": "median of %d runs, %.1f s apart" % (len(runs), args.e2e_pause), "walls_s": [r_["wall_s"] for r_ in runs],
+               # the FIRST timed run: page cache of the FASTA warm (it was just written), GPU code objects not yet cached by
+               # the driver for this program -- what a user's first start costs
+               "cold_first_run_s": runs[0]["wall_s"],
+               # where the FASTA lies: "tmpfs" = /dev/shm (memory: no disk in the read), "disk" = the temporary directory's file system
+               "fasta_on": "tmpfs" if base else "disk",
                "best_wall_s": walls[0], "phases_s": mid["phases_s"], "runtime_start_ms": mid["runtime_start_ms"],
                "exit_s": mid["exit_s"], "before_main_s": mid["before_main_s"], "runs": runs,
                "device_ready_probe_first_stream_ms": probe,
@@ -928,7 +1025,7 @@ def e2e_reference(res, tmp, args, W, both, L, nseq, cpu_base):
     try:
         if tmp and "error" not in res and not args.no_cpu_baseline:
             res["reference_same_box"] = reference_same_box(os.path.join(tmp, "s.fa"), tmp, W, both, L, nseq, res["wall_s"], cpu_base,
-                                                           res["best_wall_s"])
+                                                           res["best_wall_s"], res.get("cold_first_run_s"))
     finally:
         if tmp:
             shutil.rmtree(tmp, ignore_errors=True)
@@ -962,6 +1059,22 @@ def cpu_baseline(args, W, both, L, stress_probe=None):
     for _ in range(nsweep):
         e, lp, z = po.stats(W, counts, bgp[2], ltot)
     t_stats = (time.perf_counter() - t0) / nsweep
+    # the same two sweeps with all cores: the loops the reference runs under OpenMP (src/base_pattern.cpp:232,253,261,289);
+    # count and EM are serial in the reference whatever --threads says
+    ncores = os.cpu_count() or 1
+    po.set_threads(ncores)
+    try:
+        po.stats(W, counts, bgp[2], ltot)
+        t0 = time.perf_counter()
+        for _ in range(nsweep):
+            po.stats(W, counts, bgp[2], ltot)
+        t_stats_all = (time.perf_counter() - t0) / nsweep
+        t0 = time.perf_counter()
+        for k in range(3):
+            po.bgprob(W, k, V, both)
+        t_bgp_all = time.perf_counter() - t0
+    finally:
+        po.set_threads(1)
     t0 = time.perf_counter()
     seeds = po.select(W, z, counts, 10.0, 3, not both, True)
     t_select = time.perf_counter() - t0
@@ -976,6 +1089,11 @@ def cpu_baseline(args, W, both, L, stress_probe=None):
            "sample": "oracle (bit-exact port of the reference's serial loops, g++ -O3, 1 thread) on %d x %d bp of the same synthetic set: count %.2f s; sweep over 4^%d patterns %.3f s; %d PWMs x 10 EM iterations %.2f s"
                      % (n, L, t_count, W, t_stats, npw, t_em),
            "zscores_per_s": round(4 ** W / t_stats, 1), "em_evals_per_s": round(npw * 10 * 4 ** W / t_em, 1),
+           # the OpenMP-equivalent sweeps with --threads=all (the port's loops under OpenMP, same values)
+           "sweeps_all_threads": {"threads": ncores, "stats_sweep_s": round(t_stats_all, 5), "zscores_per_s": round(4 ** W / t_stats_all, 1),
+                                  "bgprob_tables_3_orders_s": round(t_bgp_all, 4),
+                                  "zscores_per_s_incl_bgprob_tables": round(4 ** W / (t_stats_all + t_bgp_all), 1),
+                                  "one_thread_zscores_per_s_incl_bgprob_tables": round(4 ** W / (t_stats + t_bgp), 1)},
            "port_phases_s": {"count": round(t_count, 3), "bg_counts_%d_sequences" % n_bg: round(t_bgc, 3), "bgprob_tables_3_orders": round(t_bgp, 3),
                              "stats_sweep": round(t_stats, 4), "seed_selection_%d_seeds" % len(seeds): round(t_select, 3),
                              "em_per_pwm_10_iterations": round(t_em / npw, 4), "sample_sequences": n}}

@@ -348,6 +348,14 @@ int pengk_comm_unique_id(void* id_out /* PENGK_COMM_ID_BYTES */);
 int pengk_comm_init(pengk_ctx* ctx, const void* id, int rank, int world);
 int pengk_comm_init_env(pengk_ctx* ctx);
 int pengk_comm_info(pengk_ctx* ctx, int* rank_out, int* world_out);
+/* 1 after a pengk_comm_init / pengk_comm_init_env whose deadline passed: a helper thread of this process is then still inside
+ * ncclCommInitRank (which has no deadline of its own, and no communicator yet that ncclCommAbort could be given).  Such a
+ * process must leave with _exit(): exit handlers and static destructors of HIP / RCCL under that live thread can crash or
+ * hang.  (peng_motif does; csrc/comm.hip.) */
+int pengk_comm_init_abandoned(void);
+/* ncclGetVersion's code of the librccl this process bound (0 before the first communicator call); libraries that report
+ * an API older than NCCL 2.0 are refused when they are loaded. */
+int pengk_comm_rccl_version(void);
 int pengk_comm_destroy(pengk_ctx* ctx);
 /* In-place sum over the ranks of d_counts uint32[4^W] (the global bin bound must stay below 2^32: the caller checks
  * the sum of its shards' pengk_packed.max_bin_bound), d_ltot uint64[1] and, if not NULL, d_bg uint64[84]. */

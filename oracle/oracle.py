@@ -109,6 +109,11 @@ def bg_V(n, K=2, alpha=(1.0, 1.0, 1.0), wide=False):
     return V
 
 
+def set_threads(n):
+    """Threads of the two pattern-space sweeps (bgprob, stats): the loops the reference runs under OpenMP; 1 by default."""
+    lib().po_set_threads(int(n))
+
+
 def bgprob(W, k, V, both):
     V = np.ascontiguousarray(V, np.float32)
     if len(V) < 84:

@@ -270,6 +270,12 @@ PO_API void po_bg_V64(const int64_t* n, int K, const float* alpha, float* V) { b
 // in position order; V laid out as po_bg_V.  `both` applies the strand aggregation of :268-283:
 // both twins get p[min] + p[max]; palindromes are left alone.
 // ---------------------------------------------------------------------------------------------
+// Threads for the two pattern-space sweeps below -- the loops the reference runs under OpenMP (src/base_pattern.cpp:232,
+// 253, 261 static; :289 over the initial (k+1)-mers): every pattern is independent, so the values do not depend on the
+// thread count.  1 by default (the reference's --threads default, src/Global.cpp:52); bench.py's cpu_baseline times both.
+static int g_sweep_threads = 1;
+PO_API void po_set_threads(int n) { g_sweep_threads = n < 1 ? 1 : n; }
+
 PO_API void po_bgprob(int W, int k, const float* V, int both, float* out /* 4^W */) {
   const uint64_t NP = 1ull << (2 * W);
   const float* vk[3];
@@ -280,6 +286,7 @@ PO_API void po_bgprob(int W, int k, const float* V, int both, float* out /* 4^W 
       q += 1ll << (2 * (j + 1));
     }
   }
+#pragma omp parallel for schedule(static) num_threads(g_sweep_threads)
   for (uint64_t x = 0; x < NP; ++x) {
     float pr = 1.0f;
     for (int j = 0; j <= k && j < W; ++j) pr *= vk[j][bamm_id(x, j, j)];
@@ -304,6 +311,7 @@ PO_API void po_stats(int W, const uint64_t* counts, const float* bgp, uint64_t l
                      float* logp, float* z) {
   const uint64_t NP = 1ull << (2 * W);
   const float fl = (float)ltot;
+#pragma omp parallel for schedule(static) num_threads(g_sweep_threads)
   for (uint64_t x = 0; x < NP; ++x) {
     const float mu = bgp[x] * fl;
     expected[x] = mu;

@@ -27,7 +27,7 @@ EXPORTS = [
     "pengk_pack", "pengk_pack_threads", "pengk_pack_append", "pengk_packed_free", "pengk_set_sequences", "pengk_synth_sizes", "pengk_synth_sequences",
     "pengk_count", "pengk_count_bg", "pengk_mirror_counts", "pengk_bg_count", "pengk_bg_model", "pengk_pattern_stats",
     "pengk_seed_candidates", "pengk_iupac_aggregate", "pengk_em", "pengk_em_device", "pengk_test_em_generation", "pengk_sequential_sum_f32", "pengk_motif_similarity", "pengk_selftest_division",
-    "pengk_comm_unique_id", "pengk_comm_init", "pengk_comm_init_env", "pengk_comm_info", "pengk_comm_destroy",
+    "pengk_comm_unique_id", "pengk_comm_init", "pengk_comm_init_env", "pengk_comm_info", "pengk_comm_init_abandoned", "pengk_comm_rccl_version", "pengk_comm_destroy",
     "pengk_allreduce_tables", "pengk_comm_check_bin_bound", "pengk_allgather",
     "pengk_comm_host_init_env", "pengk_comm_host_info", "pengk_comm_host_allgather", "pengk_comm_host_allreduce_u64",
     "pengk_comm_host_shutdown",

@@ -66,9 +66,13 @@ struct Rccl {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
+  int (*CommAbort)(rccl_comm) = nullptr;  // (optional)
+  int version = 0;
 };
 
 Rccl g_rccl;
+int g_init_abandoned = 0;  // a helper thread of pengk_comm_init is still inside ncclCommInitRank (its deadline passed)
 
 int load_rccl() {
   if (g_rccl.handle) return PENGK_OK;
@@ -103,7 +107,19 @@ int load_rccl() {
   PENGK_SYM(GroupStart, "ncclGroupStart");
   PENGK_SYM(GroupEnd, "ncclGroupEnd");
   PENGK_SYM(GetErrorString, "ncclGetErrorString");
+  PENGK_SYM(GetVersion, "ncclGetVersion");
 #undef PENGK_SYM
+  *(void**)(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
+  // The entry points above are declared by hand with the NCCL 2.x ABI (128-byte id, ncclDataType_t / ncclRedOp_t values):
+  // the library says which NCCL API it implements, and anything older than 2.0 is refused.  (ncclGetVersion's code is
+  // major * 1000 + minor * 100 + patch up to 2.8 and major * 10000 + minor * 100 + patch from 2.9 on: either way >= 2000.)
+  int v = 0;
+  if (g_rccl.GetVersion(&v) != 0 || v < 2000)
+    return fail(PENGK_ERR_DEVICE, "librccl reports NCCL API version code %d: this library binds the 2.x ABI", v);
+  g_rccl.version = v;
+  if (!getenv("PENGK_COMM_QUIET"))
+    fprintf(stderr, "[pengk] librccl loaded: NCCL API version code %d (%d.%d.%d)%s\n", v, v >= 20000 ? v / 10000 : v / 1000,
+            v >= 20000 ? (v / 100) % 100 : (v / 100) % 10, v % 100, g_rccl.CommAbort ? "" : ", no ncclCommAbort");
   g_rccl.handle = h;
   return PENGK_OK;
 }
@@ -543,9 +559,15 @@ int pengk_comm_init(pengk_ctx* ctx, const void* id_bytes, int rank, int world) {
   }).detach();
   {
     std::unique_lock<std::mutex> lock(call->mu);
-    if (!call->cv.wait_for(lock, std::chrono::seconds(timeout_s), [&] { return call->done; }))
+    if (!call->cv.wait_for(lock, std::chrono::seconds(timeout_s), [&] { return call->done; })) {
+      // The helper thread is still inside ncclCommInitRank and stays there: there is no communicator yet that ncclCommAbort
+      // could be given.  A process in this state must not run its exit handlers (HIP's and RCCL's static destructors
+      // under a live thread inside RCCL can crash or hang, which would defeat the deadline): callers ask
+      // pengk_comm_init_abandoned() and leave with _exit (host/device.cpp does).
+      g_init_abandoned = 1;
       return fail(PENGK_ERR_DEVICE, "ncclCommInitRank: rank %d of %d still waiting for the other ranks after %d s", rank, world,
                   timeout_s);
+    }
     if (call->result != 0)
       return fail(PENGK_ERR_DEVICE, "ncclCommInitRank: %s", call->result < 0 ? "hipSetDevice failed" : g_rccl.GetErrorString(call->result));
     ctx->comm = call->comm;
@@ -598,6 +620,10 @@ int pengk_comm_init_env(pengk_ctx* ctx) {
   if (rc) return rc;
   if (msg.rc) return rank == 0 ? msg.rc : fail(PENGK_ERR_DEVICE, "rank 0 could not create an RCCL id");
   lock.unlock();
+  {  // test hook: this rank dies here -- between "everybody can" and ncclCommInitRank (tests/test_gpu_multirank.py)
+    const char* t = getenv("PENGK_COMM_TEST_DIE_BEFORE_INIT");
+    if (t && *t && atoi(t) == rank) _exit(3);
+  }
   const int32_t inited = pengk_comm_init(ctx, &msg.id, rank, world);
   // ... and nobody USES the communicator before every rank has one: a one-sided failure inside ncclCommInitRank
   // surfaces on all ranks here, within the host channel's deadline
@@ -621,6 +647,10 @@ int pengk_comm_info(pengk_ctx* ctx, int* rank_out, int* world_out) {
   if (world_out) *world_out = single(ctx) ? 1 : ctx->comm_world;
   return PENGK_OK;
 }
+
+int pengk_comm_init_abandoned(void) { return g_init_abandoned; }
+
+int pengk_comm_rccl_version(void) { return g_rccl.handle ? g_rccl.version : 0; }
 
 int pengk_comm_destroy(pengk_ctx* ctx) {
   if (!ctx) return PENGK_OK;

@@ -64,6 +64,13 @@ void finish_ranks() {
 void check(int rc, const char* what) {
   if (rc == PENGK_OK) return;
   std::cerr << "Error: " << what << " failed: " << pengk_error_name(rc) << ": " << pengk_last_error() << std::endl;
+  // A communicator set-up whose deadline passed has left a helper thread inside ncclCommInitRank: no exit handlers, no
+  // static destructors of HIP / RCCL under it (they can crash or hang, and a hang would defeat the deadline)
+  if (pengk_comm_init_abandoned()) {
+    std::cerr.flush();
+    std::cout.flush();
+    _exit(1);
+  }
   exit(1);
 }
 

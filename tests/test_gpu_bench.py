@@ -67,6 +67,20 @@ def test_single_rank_json_contract():
     assert "not a BASELINE.json configuration" in d["config"]["workload"]
     assert rf["traffic"] is None and "roofline_issue" not in d
     assert d["roofline_em"]["parity_mode"]["frac"] > 0 and d["roofline_em"]["parity_mode"]["ms"] > 0
+    # round 5: how the exchange ran is on the top level (one rank: no communicator, no fallback); the sweep and K4 carry
+    # their own roofline objects (28 B per pattern, 16 B per visited k-mer: SURVEY.md 8d); the strong-scaled leg at one rank
+    # is the line's own step; the end-to-end leg says where its FASTA lay and what the first run cost
+    assert d["rccl_ranks"] == 0 and d["exchange_fallback"] is None
+    for key, alg in (("roofline_sweep", 28 * 4 ** 10), ):
+        r_ = d[key]
+        assert r_["bound"] == "hbm" and r_["algorithmic_bytes_per_launch"] == alg and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-4
+    assert d["roofline_k4"]["bound"] == "hbm" and d["roofline_k4"]["achieved"] > 0 and d["roofline_k4"]["algorithmic_bytes_per_call"] % 16 == 0
+    assert c3["roofline_sweep"]["algorithmic_bytes_per_launch"] == 28 * 4 ** 12 and "weak" in c3["scaling"] and "strong" in c4["scaling"]
+    st = d["components"]["config2_strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 1 and st["speedup_vs_1rank"] == 1.0 and st["ms_per_step"] == d["ms_per_step"]
+    assert e2e["fasta_on"] in ("tmpfs", "disk") and e2e["cold_first_run_s"] == e2e["walls_s"][0] and same["speedup_cold"] > 0
+    al = cb["sweeps_all_threads"]
+    assert al["threads"] >= 1 and al["zscores_per_s"] > 0 and al["bgprob_tables_3_orders_s"] > 0
 
 
 def test_two_rank_rehearsal_allreduces_the_tables():
@@ -130,6 +144,46 @@ def test_one_rank_through_the_rccl_code_path_of_the_bench():
     assert forced["checks"] == plain["checks"]
 
 
+def test_strong_scaled_leg_at_one_rank_through_the_communicator():
+    """components.config2_strong with the one rank a one-GPU box can hold, through the N > 1 code path
+    (PENGK_BENCH_FORCE_COMM=1): the set "split" one way, the exchange through the library's RCCL communicator, and beside
+    it the same set on one rank without any exchange -- same bits, a ratio near 1, and the top-level flags say that the
+    exchange really ran in the library."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    d = _bench(["--gpus", "1", "--nseq", "200000", "--strong", "1"], env=dict(os.environ, PENGK_BENCH_FORCE_COMM="1"),
+               launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port)])
+    assert d["rccl_ranks"] == 1 and d["exchange_fallback"] is None
+    st = d["components"]["config2_strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 1 and st["same_bits_as_1rank"]["ok"] is True, st
+    assert st["ms_per_step"] > 0 and st["ms_1rank"] > 0 and 0.3 < st["speedup_vs_1rank"] < 3.0
+    assert st["exchange_bytes"] == 4 * 4 ** 10 + 680
+
+
+def test_strong_scaled_leg_on_two_ranks():
+    """The 300k-sequence set split over two ranks (gloo rehearsal: both on the box's one GPU, the exchange through the
+    host): after the exchange both hold the table one rank computes from the whole set -- counts, background counters, z
+    and the PWMs of the EM, sha256 for sha256 --, and the line reports the two step times and their ratio."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    d = _bench(["--gpus", "2", "--nseq", "300000", "--strong", "1"], env=dict(os.environ, PENGK_BENCH_BACKEND="gloo"),
+               launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port)])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 0 and d["exchange_fallback"] is None and d["scaling"] == "weak"
+    st = d["components"]["config2_strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["same_bits_as_1rank"]["ok"] is True, st
+    assert all(st["same_bits_as_1rank"]["parts"].values()) and set(st["same_bits_as_1rank"]["parts"]) == {"sha_counts", "sha_z", "sha_bg_ltot", "sha_em_pwms"}
+    assert st["ms_per_step"] > 0 and st["ms_1rank"] > 0 and st["speedup_vs_1rank"] > 0
+    # the whole set's table is also what ONE rank of the weak layout holds for 300k sequences
+    one = _bench(["--nseq", "300000"])
+    assert one["checks"]["sha_counts"] and one["components"]["config2_strong"]["n_gpus"] == 1
+
+
 def test_bench_exchange_safety_net_when_the_library_communicator_fails():
     """If pengk_comm_init fails on some rank at N > 1 the ranks agree (an all_reduce of a flag) to run the exchange as
     torch.distributed's RCCL all_reduce of the same device buffers, and the JSON line says so: forced here with the one
@@ -144,6 +198,8 @@ def test_bench_exchange_safety_net_when_the_library_communicator_fails():
     plain = _bench(["--nseq", "200000"])
     assert broken["config"]["exchange"].startswith("RCCL via torch.distributed all_reduce (fallback")
     assert broken["checks"] == plain["checks"]
+    # ... and nobody can take such a line for one that went through the library's exchange
+    assert broken["rccl_ranks"] == 0 and "PENGK_BENCH_BREAK_COMM" in broken["exchange_fallback"] and plain["exchange_fallback"] is None
 
 
 def test_bench_starts_its_own_launcher_for_gpus_n():

@@ -206,6 +206,29 @@ def test_a_rank_without_rccl_ends_every_rank_before_anyone_enters_comminit(tmp_p
     assert b"forced by PENGK_COMM_TEST_FAIL_LOAD" in res[1][1], res[1][1][-600:]
 
 
+def test_a_rank_that_dies_in_front_of_comminit_ends_the_other_within_the_deadline(tmp_path):
+    """RCCL transport, two ranks: rank 1 dies AFTER every rank has agreed that it can create the communicator and before it
+    enters ncclCommInitRank (PENGK_COMM_TEST_DIE_BEFORE_INIT).  Rank 0 is then inside ncclCommInitRank -- which has no
+    deadline of its own -- with a peer that never comes: its helper thread stays there, the call returns after
+    PENGK_COMM_TIMEOUT seconds, and peng_motif leaves with _exit(1) (no exit handlers under the live thread inside RCCL:
+    host/device.cpp, pengk_comm_init_abandoned).  Both ranks are gone, non-zero, well inside the test's limit."""
+    port = free_port()
+    import time
+    t0 = time.time()
+    procs = []
+    for rank in range(2):
+        env = clean_env(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                        PENGK_COMM_TRANSPORT="rccl", PENGK_COMM_TIMEOUT="6", PENGK_COMM_TEST_DIE_BEFORE_INIT="1")
+        procs.append(subprocess.Popen([CLI, os.path.join(GOLD, "MafK_100seqs.fasta"), "-w", "8"], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, env=env))
+    res = [p.communicate(timeout=120) + (p.returncode,) for p in procs]
+    took = time.time() - t0
+    assert res[1][2] == 3, res[1]
+    assert res[0][2] == 1, res[0]
+    assert took < 60, took  # the deadline (6 s) plus the start of two processes, not a hang
+    assert b"pengk_comm_init_env failed" in res[0][1], res[0][1][-600:]
+
+
 def test_comminit_has_a_deadline():
     """pengk_comm_init with an id whose other rank never joins: an error after PENGK_COMM_TIMEOUT seconds, not a process
     parked inside ncclCommInitRank (the call runs on a helper thread; the process leaves with os._exit, as a rank does
@@ -219,8 +242,10 @@ ctx = pk.Context(0)
 buf = C.create_string_buffer(128)
 pk._check(L.pengk_comm_unique_id(buf))
 t0 = time.time()
+before = L.pengk_comm_init_abandoned()
 rc = L.pengk_comm_init(ctx.h, buf.raw, 0, 2)
 print("RC", rc, "%%.1f" %% (time.time() - t0), L.pengk_last_error().decode(), flush=True)
+print("ABANDONED", before, L.pengk_comm_init_abandoned(), "VERSION", L.pengk_comm_rccl_version(), flush=True)
 os._exit(0)
 """ % ROOT
     import sys
@@ -231,6 +256,10 @@ os._exit(0)
     assert r.returncode == 0 and len(line) == 1, (out, r.stderr.decode()[-800:])
     rc, secs = line[0].split()[1:3]
     assert int(rc) != 0 and 3.5 <= float(secs) < 30 and "still waiting for the other ranks" in line[0], out
+    # the process knows that a helper thread of it is still inside ncclCommInitRank (peng_motif then leaves with _exit,
+    # host/device.cpp: check), and which NCCL API the bound librccl implements (>= 2.0, or it would have been refused)
+    ab, = [l.split() for l in out.splitlines() if l.startswith("ABANDONED ")]
+    assert ab[1] == "0" and ab[2] == "1" and int(ab[4]) >= 2000, ab
 
 
 def _prefix_row(job, k):
