@@ -958,7 +958,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
 #pragma unroll 1
   for (uint32_t task = wave, i = 0; task < G::CELLS; task += SPAN_EVAL_WAVES, ++i) {
     const uint32_t p = task >> 2, j = task & 3u;
-    if (block_of(task) == 0u) continue;  // (folded from zero by the workgroups behind the spans)
+    if (block_of(task) == 0u) continue;  // (folded from zero by the workgroups in front of the spans')
     seqsum::BlockRecord* r = cells + (size_t)cell_of(task) * G::NBLK + block_of(task);
     const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)binades, (int)i);
     if (e == seqsum::NO_BINADE) {
@@ -1765,6 +1765,8 @@ int launch_w(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float saturation, flo
 
 int launch_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float saturation, float threshold, int max_it,
               const uint32_t* d_counts, const float* d_bg, int32_t* d_state, float* d_change) {
+  // (pengk_get_info "em_*": what the chains of THIS call met -- zero for the modes that have no chains)
+  if (ctx->d_em_counters) PENGK_HIP(hipMemsetAsync(ctx->d_em_counters, 0, EM_COUNTERS * sizeof(unsigned long long), ctx->stream));
   switch (W) {
     case 2:
       hipLaunchKernelGGL(em_init_kernel, dim3((unsigned)((n_pwm + 255) / 256)), dim3(256), 0, ctx->stream, (int)n_pwm, W, threshold, max_it,

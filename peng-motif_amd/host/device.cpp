@@ -330,6 +330,23 @@ const PackedInput* finish_streaming_pack(SequenceSet* set) {
   // 33 ms of a blocked pengk_set_sequences -- while the exiting process returns the same pages for nothing
   // (tools/e2e_ab.sh, profiles/r04_e2e_experiments.log: median 0.45 / 0.43 / 0.32 s with sync / async / no release on a
   // noisy box).  ~Stream (PENGK_FULL_TEARDOWN) releases them.
+  // That trade is for inputs of the bench's size.  A large input must not keep bases / 4 bytes plus the item table mapped
+  // for the rest of the run (~5 GB for a single-process 100M x 200 bp input, ~0.6 GB per configs[3] shard): above
+  // PENGK_HOST_RELEASE_MB (default 1024 MiB) the host copies go back now -- such a run takes seconds, the shoot-downs
+  // ~60 ms per GB.  0 = never (the round-4 behaviour), 1 = always.
+  {
+    size_t limit_mb = 1024;
+    if (const char* e = std::getenv("PENGK_HOST_RELEASE_MB")) limit_mb = (size_t)std::strtoull(e, nullptr, 10);
+    const size_t held = st->words_bytes + st->items_bytes;
+    if (limit_mb != 0 && held > (limit_mb << 20)) {
+      if (st->target.words) munmap(st->target.words, st->words_bytes);
+      if (st->target.items) munmap(st->target.items, st->items_bytes);
+      st->target.words = nullptr;
+      st->target.items = nullptr;
+      if (std::getenv("PENGK_TIMING"))
+        std::cerr << "[timing] (host copies of the packed input released: " << (held >> 20) << " MiB)" << std::endl;
+    }
+  }
   if (!st->in.d_words) return nullptr;  // no records at all on this rank: the staged path handles the empty shard
   return &st->in;
 }

@@ -84,20 +84,24 @@ inline Entry* partition(Entry* first, Entry* last, const Entry* pivot) {
 inline Entry* partition_parallel(Entry* first, Entry* last, const Entry* pivot, unsigned nt) {
   const size_t n = (size_t)(last - first);
   const float pz = pivot->z;
-  // stopper lists per chunk, in uninitialised storage (a vector would zero-fill what is overwritten at once)
+  // stopper lists per chunk, in uninitialised storage (a vector would zero-fill what is overwritten at once): ONE block
+  // for all of them, 8 bytes per entry of the range, allocated here -- a thread body must not throw -- and if it is not
+  // to be had the scalar loop does the work (same arrangement, same return value)
   struct List {
-    std::unique_ptr<uint32_t[]> p;
+    uint32_t* p = nullptr;
     size_t n = 0;
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
     uint32_t operator[](size_t i) const { return p[i]; }
   };
+  std::unique_ptr<uint32_t[]> block(new (std::nothrow) uint32_t[2 * (n + nt)]);
+  if (!block) return partition(first, last, pivot);
   std::vector<List> Ls(nt), Rs(nt);
   {
     auto scan = [&](unsigned t) {
       const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
-      uint32_t* l = new uint32_t[hi - lo + 1];
-      uint32_t* r = new uint32_t[hi - lo + 1];
+      uint32_t* l = block.get() + 2 * (lo + t);  // (chunk t's two lists of hi - lo + 1 entries: the chunks in front hold 2 (lo + t))
+      uint32_t* r = l + (hi - lo + 1);
       size_t nl = 0, nr = 0;
       for (size_t i = lo; i < hi; ++i) {  // (branch-free appends: a random table mispredicts every other compare)
         const float zi = first[i].z;
@@ -106,9 +110,9 @@ inline Entry* partition_parallel(Entry* first, Entry* last, const Entry* pivot, 
         r[nr] = (uint32_t)i;
         nr += !(pz > zi);
       }
-      Ls[t].p.reset(l);
+      Ls[t].p = l;
       Ls[t].n = nl;
-      Rs[t].p.reset(r);
+      Rs[t].p = r;
       Rs[t].n = nr;
     };
     std::vector<std::thread> th;
@@ -189,7 +193,9 @@ inline unsigned partition_threads(size_t n) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     return e && *e ? (unsigned)std::max(1, std::atoi(e)) : std::min(16u, hw);
   }();
-  if (n < ((size_t)1 << 18) || n >= ((size_t)1 << 31)) return 1u;
+  // (above 2^27 entries -- the first partition of a W = 14 table -- the stopper lists would take more than a GiB beside the
+  // table: that one range goes through the scalar loop, its halves through the threads)
+  if (n < ((size_t)1 << 18) || n > ((size_t)1 << 27)) return 1u;
   return (unsigned)std::min<size_t>(cap, n >> 17);
 }
 

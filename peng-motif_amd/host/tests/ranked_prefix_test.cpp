@@ -47,7 +47,7 @@ int check(const std::vector<float>& z, float thr, const char* what) {
 int main() {
   std::mt19937_64 rng(12345);
   int cases = 0;
-  // (from 2^17 entries on the large partitions run on several threads: ranked_prefix.h, partition_parallel)
+  // (from 2^18 entries on the large partitions run on several threads: ranked_prefix.h, partition_parallel)
   const size_t sizes[] = {0, 1, 2, 15, 16, 17, 18, 33, 100, 1000, 4096, 65536, 131071, 131072, 131073, 300001, 1u << 20, (1u << 22) + 5};
   for (size_t n : sizes) {
     for (int style = 0; style < 6; ++style) {
