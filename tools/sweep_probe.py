@@ -24,7 +24,11 @@ def main():
     counts, ltot, bg = ctx.count_bg(True)
     ctx.mirror(W, counts)
     V = ctx.bg_model(bg, 2)
-    ctx.set_option("stats_impl", a.impl)
+    if a.impl:  # (option of the round-5 experiment, profiles/r05_sweep_tile_pairs.patch; the library has one sweep kernel)
+        try:
+            ctx.set_option("stats_impl", a.impl)
+        except pk.PengkError:
+            pass
     out = ctx.pattern_stats(W, True, 2, 2, V, ltot, counts)
     t0, t1 = ctx.timer(), ctx.timer()
     ms = []
