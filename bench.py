@@ -1061,7 +1061,8 @@ def cpu_baseline(args, W, both, L, stress_probe=None):
     t_stats = (time.perf_counter() - t0) / nsweep
     # the same two sweeps with all cores: the loops the reference runs under OpenMP (src/base_pattern.cpp:232,253,261,289);
     # count and EM are serial in the reference whatever --threads says
-    ncores = os.cpu_count() or 1
+    # (the cores this process may run on -- a one-GPU lease is a share of the host --, not the host's hardware threads)
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     po.set_threads(ncores)
     try:
         po.stats(W, counts, bgp[2], ltot)
@@ -1090,7 +1091,7 @@ def cpu_baseline(args, W, both, L, stress_probe=None):
                      % (n, L, t_count, W, t_stats, npw, t_em),
            "zscores_per_s": round(4 ** W / t_stats, 1), "em_evals_per_s": round(npw * 10 * 4 ** W / t_em, 1),
            # the OpenMP-equivalent sweeps with --threads=all (the port's loops under OpenMP, same values)
-           "sweeps_all_threads": {"threads": ncores, "stats_sweep_s": round(t_stats_all, 5), "zscores_per_s": round(4 ** W / t_stats_all, 1),
+           "sweeps_all_threads": {"threads": ncores, "host_hardware_threads": os.cpu_count(), "stats_sweep_s": round(t_stats_all, 5), "zscores_per_s": round(4 ** W / t_stats_all, 1),
                                   "bgprob_tables_3_orders_s": round(t_bgp_all, 4),
                                   "zscores_per_s_incl_bgprob_tables": round(4 ** W / (t_stats_all + t_bgp_all), 1),
                                   "one_thread_zscores_per_s_incl_bgprob_tables": round(4 ** W / (t_stats + t_bgp), 1)},

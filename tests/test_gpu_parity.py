@@ -972,7 +972,7 @@ def test_em_serial_batches_on_several_streams(ctx, golden_dir):
 
 @pytest.mark.parametrize("name", ["mafk100_w8_both", "mafk_w10_plus"])
 def test_em_serial_scan_equals_the_dependent_addition_fold(ctx, golden_dir, name):
-    """The serial mode sums a cell's weights with a wave-wide scan (csrc/seqsum.h, option em_serial_scan = 1, default)
+    """The serial mode sums a cell's weights with a wave-wide scan (csrc/seqsum.h; generation 1 of pengk_test_em_generation, the product's path at W = 8)
     or, as in the first rounds, by dependent additions (0).  Both must give the same bits on every PWM -- including
     degenerate PWMs whose weights are NaN (a zero PWM entry over a zero background entry: 0 / 0), which the scan hands
     to the dependent-addition fold PWM by PWM."""

@@ -1,6 +1,8 @@
-"""Differential soak of the serial EM: the scan (csrc/seqsum.h, em_serial_scan = 1) against the dependent-addition fold
-(em_serial_scan = 0) on random count tables, backgrounds and PWMs (GPU box) -- PWMs, iteration counts and `change` must be
-equal bit for bit.  usage: python tests/tools/em_scan_fuzz.py FIRST_SEED SECONDS [W,W,...]   (default 8,10,10)"""
+"""Differential soak of the serial EM: the library's scheme (blocks evaluated ahead of their chain, 2), its two-launch variant
+(3) and the scan block after block (generation 1) against the dependent-addition fold (generation 0) on random count
+tables, backgrounds and PWMs (GPU box) -- PWMs, iteration counts and `change` must be equal bit for bit.  Wrong binade
+estimates (em_test_skew) and timed-out look-backs (em_test_lookback) are part of the mix.
+usage: python tests/tools/em_scan_fuzz.py FIRST_SEED SECONDS [W,W,...]   (default 8,10,10)"""
 import os
 import sys
 import time
@@ -42,23 +44,26 @@ while time.time() < t_end:
     bgd = pk.DeviceArray.from_host(ctx, bg)
     out = {}
     skew = int(rng.choice([0, 0, 1, 3, 17]))   # test hook: wrong binade estimates for every skew-th block (mode 2 only)
-    for scan in (2, 1, 0):
+    lookback = int(rng.choice([0, 0, 1, 5]))
+    for scan in (3, 2, 1, 0):
         ctx.test_em_generation(scan)
-        ctx.set_option("em_test_skew", skew if scan == 2 else 0)
+        ctx.set_option("em_test_skew", skew if scan >= 2 else 0)
+        ctx.set_option("em_test_lookback", lookback if scan == 3 else 0)
         out[scan] = ctx.em(W, pw, counts, bgd, sat, thr, it)
     ctx.test_em_generation(2)
     ctx.set_option("em_test_skew", 0)
-    bad_modes = [k for k in (1, 2) if not (out[k][0].tobytes() == out[0][0].tobytes() and out[k][1].tolist() == out[0][1].tolist()
+    ctx.set_option("em_test_lookback", 0)
+    bad_modes = [k for k in (1, 2, 3) if not (out[k][0].tobytes() == out[0][0].tobytes() and out[k][1].tolist() == out[0][1].tolist()
                                            and out[k][2].tobytes() == out[0][2].tobytes())]
     if bad_modes:
         # once more, all three: which of them moves?
         again = {}
-        for scan in (2, 1, 0):
+        for scan in (3, 2, 1, 0):
             ctx.test_em_generation(scan)
             again[scan] = ctx.em(W, pw, counts, bgd, sat, thr, it)
         ctx.test_em_generation(2)
-        print("MISMATCH seed", seed, "W", W, "kind", kind, "skew", skew, "n", n, "it", it, "thr", thr, "modes that differ from the fold:", bad_modes,
-              "; repeated run equals first run per mode:", {k: again[k][0].tobytes() == out[k][0].tobytes() for k in (2, 1, 0)})
+        print("MISMATCH seed", seed, "W", W, "kind", kind, "skew", skew, "lookback", lookback, "n", n, "it", it, "thr", thr, "modes that differ from the fold:", bad_modes,
+              "; repeated run equals first run per mode:", {k: again[k][0].tobytes() == out[k][0].tobytes() for k in (3, 2, 1, 0)})
         mismatches += 1
         if mismatches >= 5:
             sys.exit(1)
@@ -69,4 +74,4 @@ while time.time() < t_end:
         t_print = time.time()
 if mismatches:
     sys.exit(1)
-print("EM scan fuzz: seeds %d..%d, %d PWMs, scan (blocks ahead / block after block) == dependent fold bit for bit" % (seed0, seed - 1, n_pwm_total))
+print("EM scan fuzz: seeds %d..%d, %d PWMs, blocks ahead (three launches / two launches) == block after block == dependent fold bit for bit" % (seed0, seed - 1, n_pwm_total))

@@ -12,7 +12,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         if "em_" in r["Kernel_Name"]:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), re.search(r"(em_\w+)", r["Kernel_Name"]).group(1)))
 rows.sort()
-last = max(i for i, r in enumerate(rows) if r[3] == "em_init_kernel")
+last = max(i for i, r in enumerate(rows) if r[3] in ("em_init_kernel", "em_serial_setup_kernel"))  # (a call's first kernel)
 rows = rows[last:]
 t0 = rows[0][0]
 for s, e, q, k in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 80]:

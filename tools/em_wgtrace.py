@@ -2,7 +2,7 @@
 """Where the microseconds of the blocks-ahead EM's kernels go, workgroup by workgroup (GPU box, developer build):
     PENGK_BUILD_OUT=$PWD/ablation_libs/wgtrace.so PENGK_EXTRA_FLAGS=-DPENGK_WG_TRACE python peng-motif_amd/build.py --force
     PENGK_LIB=$PWD/ablation_libs/wgtrace.so python tools/em_wgtrace.py [--W 10] [--pwms 16] [--streams 1] [--iter 3]
-With -DPENGK_WG_TRACE every workgroup of em_weights_span_kernel / em_span_eval_kernel / em_chain_kernel records its start
+With -DPENGK_WG_TRACE every workgroup of em_weights_span_kernel / em_span_eval_kernel (or em_span_fused_kernel) / em_chain_store_kernel records its start
 and end (s_memtime) and its XCC (csrc/em.hip, WgTrace).  One pengk_em call is traced; the launches of iteration `--iter`
 are printed: when the workgroups started (how many rounds a kernel really takes), how long they ran, and for the
 evaluation how long a span was on its way."""
