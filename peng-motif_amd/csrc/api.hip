@@ -109,10 +109,6 @@ int pengk_create(int device, pengk_ctx** out) {
   if (!c) return fail(PENGK_ERR_NOMEM, "pengk_create: out of host memory");
   c->device = device;
   c->num_cu = prop.multiProcessorCount;
-  if (const char* e = getenv("PENGK_W12_CHUNKS")) {  // (tuning: pieces of the W = 12 count, option "w12_chunks")
-    const int v = atoi(e);
-    if (v >= 1 && v <= 8) c->w12_chunks = v;
-  }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -147,9 +143,6 @@ int pengk_destroy(pengk_ctx* ctx) {
     if (ctx->em_join[l]) (void)hipEventDestroy(ctx->em_join[l]);
   }
   if (ctx->em_fork) (void)hipEventDestroy(ctx->em_fork);
-  if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-  for (int l = 0; l < 9; ++l)
-    if (ctx->aux_events[l]) (void)hipEventDestroy(ctx->aux_events[l]);
   if (ctx->d_misc) (void)hipFree(ctx->d_misc);
   if (ctx->d_keys) (void)hipFree(ctx->d_keys);
   if (ctx->d_iupac_big) (void)hipFree(ctx->d_iupac_big);
@@ -177,11 +170,6 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
   }
   if (strcmp(name, "key_cap_override") == 0) {
     ctx->key_cap_override = (uint64_t)value;
-    return PENGK_OK;
-  }
-  if (strcmp(name, "w12_chunks") == 0) {
-    if (value < 1 || value > 8) return fail(PENGK_ERR_ARG, "w12_chunks must be 1 .. 8");
-    ctx->w12_chunks = (int)value;
     return PENGK_OK;
   }
   if (strcmp(name, "em_fast") == 0) {

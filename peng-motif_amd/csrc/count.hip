@@ -170,9 +170,7 @@ struct Suppress {
 template <int W, bool BOTH, bool BG, class Emit>
 __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32, const uint64_t* __restrict__ items,
                                            uint32_t n_items, unsigned long long* __restrict__ ltot,
-                                           uint32_t* __restrict__ defer, Emit& emit, uint32_t item0 = 0u) {
-  // (item0: `items` is a piece of the attached item table that starts at its entry item0 -- the defer list names items by
-  // their index in the whole table)
+                                           uint32_t* __restrict__ defer, Emit& emit) {
   using G = Geo<W>;
   const BgCount<W, BG> bgc{threadIdx.x >> 6};
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,7 +231,7 @@ __device__ __forceinline__ void scan_items(const uint32_t* __restrict__ words32,
       }
       if (cont && dirty) {  // cannot certify the ring: hand the item to the exact fallback
         const uint32_t slot = atomicAdd(&defer[0], 1u);
-        defer[1 + slot] = it + item0;
+        defer[1 + slot] = it;
         nw = 0;
       }
     } else {
@@ -688,15 +686,14 @@ __global__ __launch_bounds__(64 * SCATTER12L1_WPW) void count_scatter12_kernel(c
                                                               uint32_t* __restrict__ keys, uint32_t slice_cap,
                                                               uint32_t* __restrict__ slice_fill, uint32_t* __restrict__ hist,
                                                               unsigned long long* __restrict__ ltot,
-                                                              uint32_t* __restrict__ defer, uint32_t* __restrict__ bg_partials,
-                                                              uint32_t item0) {
+                                                              uint32_t* __restrict__ defer, uint32_t* __restrict__ bg_partials) {
   Scatter12Emit::init_lds();
   bg_begin<BG>();
   __syncthreads();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   Scatter12Emit e{keys, slice_cap, slice_fill, hist, wave, threadIdx.x & 63u, blockIdx.x * (uint32_t)SCATTER12L1_WPW + wave, 0u};
   e.bind();
-  scan_items<12, BOTH, BG>(words32, items, n_items, ltot, defer, e, item0);
+  scan_items<12, BOTH, BG>(words32, items, n_items, ltot, defer, e);
   e.drain();
   bg_end<BG>(bg_partials);
 }
@@ -1285,30 +1282,17 @@ int launch_partition_w(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
 }
 
 // W = 12: scan -> 32 coarse buckets of 32-bit keys -> 16 fine buckets each of 16-bit keys -> 512 LDS histograms
-// W = 12 in PIECES (option w12_chunks = C > 1): the item table is cut into C pieces; piece c's scan (level 1) runs on the
-// context's stream, its level 2 and its pass B on a second stream behind an event -- so that the level-2 kernel of piece c,
-// which streams keys at the HBM rate and issues little, runs BESIDE the scan of piece c + 1, which issues at its limit and
-// moves few bytes.  Nothing but stream order and events: no flags, no polling, nothing that can wait for a workgroup that
-// never comes.  The scan then leaves room for one level-2 workgroup per CU (one workgroup fewer per CU); every piece has its
-// own key regions (the same bytes in all as in one piece), pass B adds every piece's buckets into the same table.
 int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d_ltot, uint32_t n_items, uint64_t* d_bg) {
   const uint32_t np = 1u << 24;
   const uint32_t* w32 = (const uint32_t*)ctx->d_words;
   constexpr uint32_t TPB1 = 64u * SCATTER12L1_WPW;
   constexpr uint32_t NB1 = Split12L1::NB, NB2 = Split12L2::NB;
-  uint32_t C = ctx->w12_chunks < 1 ? 1u : (uint32_t)ctx->w12_chunks;
-  if (C > 8u) C = 8u;
-  if (n_items < C * 4096u) C = 1u;
-  const uint32_t items_per = (n_items + C - 1) / C;
-  const uint32_t blocks_needed = (items_per + TPB1 - 1) / TPB1;
+  const uint32_t blocks_needed = (n_items + TPB1 - 1) / TPB1;
   constexpr uint32_t lds_per_wg1 = (uint32_t)(sizeof(ScatterShared<Split12L1::NBITS, SCATTER12L1_WPW, uint32_t>) + sizeof(BgLds) + 511u) & ~511u;
-  uint32_t per_cu = (160u * 1024u) / lds_per_wg1;
-  if (C > 1u && per_cu > 1u) --per_cu;  // (room for a level-2 workgroup of the piece in front)
-  const uint32_t max_blocks = (uint32_t)ctx->num_cu * per_cu;
+  const uint32_t max_blocks = (uint32_t)ctx->num_cu * ((160u * 1024u) / lds_per_wg1);
   const uint32_t blocks1 = blocks_needed < max_blocks ? blocks_needed : max_blocks;
   const uint32_t n_waves1 = blocks1 * (uint32_t)SCATTER12L1_WPW;
-  const uint64_t windows_all = ctx->n_windows_hint ? ctx->n_windows_hint : ctx->n_items * (uint64_t)ctx->item_windows;
-  const uint64_t windows = (windows_all + C - 1) / C;  // per piece (pieces of equal item counts: the slices carry 50 % of slack)
+  const uint64_t windows = ctx->n_windows_hint ? ctx->n_windows_hint : ctx->n_items * (uint64_t)ctx->item_windows;
   // level-1 slices
   uint64_t share1 = windows / ((uint64_t)NB1 * n_waves1);
   uint64_t cap1_64 = share1 + share1 / 2 + 256;
@@ -1327,71 +1311,41 @@ int launch_partition12(pengk_ctx* ctx, int both, uint32_t* d_counts, uint64_t* d
   if (cap1_64 * NB1 >= (1ull << 30) || cap2_64 * NB2 >= (1ull << 31)) return fail(  // 32-bit byte offsets inside a wave's slices
       PENGK_ERR_RANGE, "shard too large for the partitioned count");
   const uint32_t cap1 = (uint32_t)cap1_64, cap2 = (uint32_t)cap2_64;
-  const size_t bytes1 = ((size_t)n_waves1 * NB1 * cap1 * sizeof(uint32_t) + 255) / 256 * 256;
-  const size_t bytes2 = ((size_t)n_waves2 * NB2 * cap2 * sizeof(uint16_t) + 255) / 256 * 256;
-  int rc = ensure_scratch(ctx, &ctx->d_keys, &ctx->keys_bytes, (size_t)C * (bytes1 + bytes2));
+  const size_t bytes1 = (size_t)n_waves1 * NB1 * cap1 * sizeof(uint32_t);
+  const size_t bytes2 = (size_t)n_waves2 * NB2 * cap2 * sizeof(uint16_t);
+  int rc = ensure_scratch(ctx, &ctx->d_keys, &ctx->keys_bytes, bytes1 + bytes2);
   if (rc) return rc;
+  uint32_t* keys1 = (uint32_t*)ctx->d_keys;
+  uint16_t* keys2 = (uint16_t*)((char*)ctx->d_keys + bytes1);
   const size_t fill1_words = ((size_t)n_waves1 * NB1 + 63) / 64 * 64, fill2_words = ((size_t)n_waves2 * NB2 + 63) / 64 * 64;
-  const size_t aux_need = ((size_t)C * (fill1_words + fill2_words) + (size_t)np) * sizeof(uint32_t);
+  const size_t aux_need = (fill1_words + fill2_words + (size_t)np) * sizeof(uint32_t);
   rc = ensure_scratch(ctx, &ctx->d_count_aux, &ctx->count_aux_bytes, aux_need);
   if (rc) return rc;
-  uint32_t* temp = (uint32_t*)ctx->d_count_aux + (size_t)C * (fill1_words + fill2_words);
+  uint32_t* fill1 = (uint32_t*)ctx->d_count_aux;
+  uint32_t* fill2 = fill1 + fill1_words;
+  uint32_t* temp = fill2 + fill2_words;
   PENGK_HIP(hipMemsetAsync(ctx->d_count_aux, 0, aux_need, ctx->stream));
   unsigned long long* lt = (unsigned long long*)d_ltot;
   uint32_t* bgp = nullptr;
   if (d_bg) {
-    rc = bg_partials_buffer(ctx, C * blocks1, &bgp);
+    rc = bg_partials_buffer(ctx, blocks1, &bgp);
     if (rc) return rc;
   }
-  hipStream_t side = ctx->stream;
-  if (C > 1u) {
-    if (!ctx->aux_stream) PENGK_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    for (uint32_t c = 0; c <= C; ++c)
-      if (!ctx->aux_events[c]) PENGK_HIP(hipEventCreateWithFlags(&ctx->aux_events[c], hipEventDisableTiming));
-    side = ctx->aux_stream;
-    // (the side stream starts behind everything enqueued so far: the cleared tables)
-    PENGK_HIP(hipEventRecord(ctx->aux_events[C], ctx->stream));
-    PENGK_HIP(hipStreamWaitEvent(side, ctx->aux_events[C], 0));
-  }
-  int rc_launch = PENGK_OK;
-  for (uint32_t c = 0; c < C && !rc_launch; ++c) {
-    const uint32_t item0 = c * items_per;
-    if (item0 >= n_items) break;
-    const uint32_t n_c = n_items - item0 < items_per ? n_items - item0 : items_per;
-    uint32_t* keys1 = (uint32_t*)((char*)ctx->d_keys + (size_t)c * (bytes1 + bytes2));
-    uint16_t* keys2 = (uint16_t*)((char*)keys1 + bytes1);
-    uint32_t* fill1 = (uint32_t*)ctx->d_count_aux + (size_t)c * (fill1_words + fill2_words);
-    uint32_t* fill2 = fill1 + fill1_words;
-    uint32_t* bgp_c = bgp ? bgp + (size_t)c * blocks1 * 84 : nullptr;
 #define TA_S12(B, G) B, G
-    PENGK_LAUNCH_BB(count_scatter12_kernel, TA_S12, both, d_bg != nullptr, dim3(blocks1), dim3(TPB1), w32, ctx->d_items + item0, n_c, keys1,
-                    cap1, fill1, d_counts, lt, ctx->d_defer, bgp_c, item0);
+  PENGK_LAUNCH_BB(count_scatter12_kernel, TA_S12, both, d_bg != nullptr, dim3(blocks1), dim3(TPB1), w32, ctx->d_items, n_items, keys1,
+                  cap1, fill1, d_counts, lt, ctx->d_defer, bgp);
 #undef TA_S12
-    if (hipGetLastError() != hipSuccess) rc_launch = fail(PENGK_ERR_DEVICE, "count_scatter12_kernel: launch failed");
-    if (C > 1u && !rc_launch) {
-      if (hipEventRecord(ctx->aux_events[c], ctx->stream) != hipSuccess || hipStreamWaitEvent(side, ctx->aux_events[c], 0) != hipSuccess)
-        rc_launch = fail(PENGK_ERR_DEVICE, "count: ordering the pieces' streams failed");
-    }
-    if (rc_launch) break;
-    hipLaunchKernelGGL(count_rescatter12_kernel, dim3(blocks2), dim3(256), 0, side, (const uint32_t*)keys1, cap1, (const uint32_t*)fill1, n_waves1,
-                       bpb1, keys2, cap2, fill2, d_counts);
-    hipLaunchKernelGGL(count_hist_kernel, dim3(512), dim3(1024), 4 << PAYLOAD_BITS, side, (const uint16_t*)keys2, cap2, n_waves2, NB2,
-                       (const uint32_t*)fill2, 1u, temp, bpb1 * 4u);
-    if (hipGetLastError() != hipSuccess) rc_launch = fail(PENGK_ERR_DEVICE, "count: level 2 / pass B launch failed");
-  }
-  if (C > 1u) {  // the side stream is ALWAYS joined: the caller reads and frees buffers on the context's stream
-    hipError_t e = hipEventRecord(ctx->aux_events[C], side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->aux_events[C], 0);
-    if (e != hipSuccess) {
-      (void)hipStreamSynchronize(side);
-      if (!rc_launch) rc_launch = hip_fail(e, "joining the count's side stream");
-    }
-  }
-  if (rc_launch) return rc_launch;
+  PENGK_HIP(hipGetLastError());
   if (d_bg) {
-    rc = bg_finish_fused(ctx, C * blocks1, d_bg);
+    rc = bg_finish_fused(ctx, blocks1, d_bg);
     if (rc) return rc;
   }
+  hipLaunchKernelGGL(count_rescatter12_kernel, dim3(blocks2), dim3(256), 0, ctx->stream, keys1, cap1, fill1, n_waves1, bpb1, keys2,
+                     cap2, fill2, d_counts);
+  PENGK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(count_hist_kernel, dim3(512), dim3(1024), 4 << PAYLOAD_BITS, ctx->stream, keys2, cap2, n_waves2, NB2, fill2, 1u,
+                     temp, bpb1 * 4u);
+  PENGK_HIP(hipGetLastError());
   hipLaunchKernelGGL(count_gather12_kernel, dim3(4096), dim3(256), 0, ctx->stream, temp, d_counts);
   PENGK_HIP(hipGetLastError());
   return PENGK_OK;

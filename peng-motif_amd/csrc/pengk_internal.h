@@ -57,9 +57,6 @@ struct pengk_ctx {
   int em_lean_div = 1;          // K5 serial mode: the weights' divisions without range scaling where a PWM's operand ranges allow (em.hip, lean_div)
   int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms
-  int w12_chunks = 1;           // W = 12 count: pieces of the item table whose level 2 runs beside the next piece's scan (count.hip)
-  hipStream_t aux_stream = nullptr;  // ... their second stream and events
-  hipEvent_t aux_events[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int scatter_blocks_per_cu = 0; // tuning hook: workgroups per CU of the partitioned scan (0 = default)
   void* d_sim = nullptr;         // motif similarity grid: PWMs | complements | lengths | sites | scores
   size_t sim_bytes = 0;

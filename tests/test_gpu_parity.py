@@ -190,56 +190,6 @@ def test_w12_two_level_partition(ctx, both):
         ctx.set_option("count_impl", 0)
 
 
-@pytest.mark.parametrize("chunks", [2, 3, 5])
-def test_w12_count_in_pieces(ctx, chunks):
-    """Option w12_chunks = C: the item table is cut into C pieces, a piece's level 2 and pass B run on a second stream beside
-    the next piece's scan (csrc/count.hip, launch_partition12: stream order and events only).  Same table, ltot and
-    background counters as one piece and as the oracle -- on random sequences in both strand modes, with split items
-    (item_windows = 64), with an overflowing key buffer, and on low-complexity sequences whose items go through the defer
-    list (which names items by their index in the WHOLE table, also from a later piece)."""
-    W = 12
-    codes, offs = po.synth(5, 0, 24000, 150)   # 24000 items at item_windows = 0, three times that at 64: every piece gets thousands
-    lc_codes, lc_offs = low_complexity_set(1212, 2800, 520)
-    ctx.set_option("count_impl", 2)
-    try:
-        for both in (True, False):
-            want, ltot = po.count(codes, offs, W, both)
-            for M, cap in ((0, 0), (64, 0), (0, 64)):
-                p = pk.Packed(codes, offs, W, M)
-                ctx.upload(p)
-                ctx.set_option("key_cap_override", cap)
-                ctx.set_option("w12_chunks", chunks)
-                counts, lt, bg = ctx.count_bg(both)
-                if both:
-                    ctx.mirror(W, counts)
-                assert int(lt.to_host()[0]) == ltot
-                assert np.array_equal(counts.to_host().astype(np.uint64), want), (both, M, cap)
-                assert np.array_equal(bg.to_host().astype(np.int64), po.bg_counts(codes, offs, 2))
-                ctx.set_option("key_cap_override", 0)
-        want, ltot = po.count(lc_codes, lc_offs, W, True)
-        p = pk.Packed(lc_codes, lc_offs, W, 64)
-        assert len(p.items) >= chunks * 4096  # (fewer items than that are counted in one piece)
-        ctx.upload(p)
-        ctx.set_option("w12_chunks", chunks)
-        counts, lt = ctx.count(True)
-        assert ctx.info("deferred_items") > 0  # the defer list was used ...
-        ctx.mirror(W, counts)
-        assert int(lt.to_host()[0]) == ltot and np.array_equal(counts.to_host().astype(np.uint64), want)  # ... with the right items
-        # a full-size sanity check against one piece: 400k x 200 bp generated on the device
-        ctx.synth(1, 77, 400_000, 200, W)
-        ctx.set_option("w12_chunks", 1)
-        one, l1, b1 = ctx.count_bg(True)
-        one = one.to_host()
-        ctx.set_option("w12_chunks", chunks)
-        got, l2, b2 = ctx.count_bg(True)
-        assert np.array_equal(one, got.to_host()) and int(l1.to_host()[0]) == int(l2.to_host()[0])
-        assert np.array_equal(b1.to_host(), b2.to_host())
-    finally:
-        ctx.set_option("w12_chunks", 1)
-        ctx.set_option("key_cap_override", 0)
-        ctx.set_option("count_impl", 0)
-
-
 def _same_bucket_sets(W, L=120):
     """Inputs that put many lanes of one wave on ONE partition bucket in the same step: the lanes of a wave hold
     consecutive scan items, so adjacent identical sequences make them emit identical keys."""
