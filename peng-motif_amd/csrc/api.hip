@@ -193,6 +193,11 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
     ctx->em_test_skew = (int)value;
     return PENGK_OK;
   }
+  if (strcmp(name, "em_head_blocks") == 0) {
+    if (value < 1 || value > 64) return PENGK_ERR_ARG;
+    ctx->em_head_blocks = (int)value;
+    return PENGK_OK;
+  }
   if (strcmp(name, "em_lean_div") == 0) {
     ctx->em_lean_div = value != 0;
     return PENGK_OK;

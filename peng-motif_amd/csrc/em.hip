@@ -825,7 +825,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
                                                                             seqsum::BlockRecord* __restrict__ rec,
                                                                             const uint32_t* __restrict__ bad, uint32_t n_pwm,
                                                                             const float* __restrict__ sums, uint32_t skew,
-                                                                            uint32_t extra_wgs) {
+                                                                            uint32_t extra_wgs, uint32_t head_blocks) {
   using G = BlockGeo<W>;
   // (run_now: the PWMs' "still running" flags behind this iteration's head, FusedState::run)
   // (consecutive workgroups go to consecutive XCDs: a PWM's spans, and behind them its chains, stay on one -- as in
@@ -848,27 +848,39 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
     if (pw >= n_pwm || wave >= 4u || cell >= G::CELLS || run_now[pw] == 0u || bad[pw]) return;
     seqsum::lds_float* buf = (seqsum::lds_float*)span + wave * seqsum::BLOCK;
     const float* w = wbuf + (size_t)pw * G::NP;
+    // ... and the `head_blocks` - 1 blocks behind it, one after the other from the exact sum: the sum doubles from block
+    // to block there (1 -> 2 -> 4 blocks' worth), so these are the blocks a chain would take the long way, several
+    // evaluations each; here they cost nothing on the iteration's critical path as long as these workgroups end before the
+    // spans' do.  A block is asked for as soon as the one before it has left the buffer for the registers.
     seqsum::Row mine;
+    seqsum::Stats st;
+    float s0 = 0.0f;
+    auto head = [&](const auto& src) {
+      src.stage(0u, lane, buf);
+#pragma unroll 1
+      for (uint32_t b = 0; b < head_blocks; ++b) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mine.read_staged(buf, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (b + 1u < head_blocks) src.stage(b + 1u, lane, buf);
+        s0 = seqsum::fold_block(mine, lane, s0, st);
+      }
+    };
     if ((cell >> 2) == 0u) {
       EmTerms0<W> src0{w, cell & 3u};
       src0.bind_stage(lane);
-      src0.stage(0u, lane, buf);
+      head(src0);
     } else {
       EmTerms<W> src{w, cell >> 2, cell & 3u};
       src.bind_stage(lane);
-      src.stage(0u, lane, buf);
+      head(src);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    mine.read_staged(buf, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    seqsum::Stats st;
-    const float s0 = seqsum::fold_block(mine, lane, 0.0f, st);
     if (lane == 0) {
       seqsum::BlockRecord out;
       out.e = seqsum::SUM_BEHIND;
       out.d0 = s0;
       out.d1 = 0.0f;
-      out.pad = 0u;
+      out.pad = head_blocks;  // (the chain starts behind them: seqsum::walk_chain)
       rec[((size_t)pw * G::CELLS + cell) * G::NBLK] = out;
     }
     PENGK_WG_TRACE_END(1, lin);
@@ -958,7 +970,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
 #pragma unroll 1
   for (uint32_t task = wave, i = 0; task < G::CELLS; task += SPAN_EVAL_WAVES, ++i) {
     const uint32_t p = task >> 2, j = task & 3u;
-    if (block_of(task) == 0u) continue;  // (folded from zero by the workgroups in front of the spans')
+    if (block_of(task) < head_blocks) continue;  // (folded from zero by the workgroups in front of the spans')
     seqsum::BlockRecord* r = cells + (size_t)cell_of(task) * G::NBLK + block_of(task);
     const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)binades, (int)i);
     if (e == seqsum::NO_BINADE) {
@@ -1604,7 +1616,7 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
             const uint64_t xwgs = (uint64_t)groups * ((B::CELLS + 3) / 4), swgs = xwgs + (uint64_t)groups * B::SPANS;
             hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(1024u, (unsigned)((swgs + 1023u) / 1024u)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
                                run_now, (const float*)tables, rec, bad_now, (uint32_t)nb, (const float*)sums,
-                               (uint32_t)ctx->em_test_skew, (uint32_t)xwgs);
+                               (uint32_t)ctx->em_test_skew, (uint32_t)xwgs, (uint32_t)std::min<uint64_t>(ctx->em_head_blocks, B::NBLK));
             hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
                                (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters);
             continue;

@@ -376,12 +376,21 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
   for (uint32_t base = 0; base < n_blocks; base += 64u) {
     // (first_records = this lane's record of the first chunk, loaded by the caller together with what else it needs)
     const uint4 r = base == 0u ? first_records : reinterpret_cast<const uint4*>(rec)[base + lane];
-    const unsigned long long open = __builtin_amdgcn_ballot_w64(r.x == NO_BINADE);
+    unsigned long long open = __builtin_amdgcn_ballot_w64(r.x == NO_BINADE);
     auto open_after = [&](uint32_t b) {  // the next block of this chunk without a binade behind block b, or NO_BINADE
       const uint32_t j = b - base;
       const unsigned long long rest = j < 63u ? open & ~((2ull << j) - 1ull) : 0ull;
       return rest ? base + (uint32_t)__builtin_ctzll(rest) : NO_BINADE;
     };
+    uint32_t j = 0;
+    if (base == 0u && (uint32_t)__builtin_amdgcn_readfirstlane((int)r.x) == SUM_BEHIND) {
+      // the first blocks were folded from zero by the kernel that evaluated the blocks (em_span_eval_kernel's extra
+      // workgroups): record 0 carries the sum behind them and their number (1..64); their own records hold nothing
+      s = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)r.y));
+      j = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w);
+      j = j < 1u ? 1u : j > 64u ? 64u : j;
+      open = j < 64u ? open & ~((1ull << j) - 1ull) : 0ull;
+    }
     if (open) {  // (nothing is in flight across chunks)
       ha = base + (uint32_t)__builtin_ctzll(open);
       src.stage(ha, lane, bufa);
@@ -389,12 +398,6 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
       if (hb != NO_BINADE) src.stage(hb, lane, bufb);
       a_first = true;
       restaged = false;
-    }
-    uint32_t j = 0;
-    if (base == 0u && (uint32_t)__builtin_amdgcn_readfirstlane((int)r.x) == SUM_BEHIND) {
-      // block 0 was folded from zero by the kernel that evaluated the blocks (em_span_eval_kernel's extra workgroups)
-      s = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)r.y));
-      j = 1u;
     }
 #pragma unroll 1
     while (j < 64u) {

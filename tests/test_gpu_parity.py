@@ -851,6 +851,52 @@ def test_em_serial_blocks_ahead_with_wrong_binade_estimates(ctx, W, skew, scheme
         assert met["restaged_waits"] > 0, met
 
 
+@pytest.mark.parametrize("W", [10, 12, 14])
+def test_em_head_blocks_folded_beside_the_evaluation(ctx, W):
+    """Option em_head_blocks = K: the first K blocks of every cell are folded one after the other from zero by extra
+    workgroups of em_span_eval_kernel (record 0 carries the sum and K, the chain starts behind them; csrc/seqsum.h
+    walk_chain).  K = 1 (round 4's layout), 2, the default, 7 and 64 (a whole 64-block chunk: at W = 10 the whole cell)
+    give the dependent-addition fold's bits, also with wrong binade estimates; fewer blocks are left to the chains."""
+    NP = 4 ** W
+    rng = np.random.default_rng(7 * W)
+    if W < 14:
+        c = rng.lognormal(1.0, 2.5, NP).astype(np.uint32)
+        bg = (rng.dirichlet(np.ones(64), size=NP // 64).reshape(-1)).astype(np.float32)
+        counts, bgd = pk.DeviceArray.from_host(ctx, c), pk.DeviceArray.from_host(ctx, bg)
+    else:  # (device-generated tables: 4^14 entries)
+        ctx.synth(11, 0, 30000, 200, W)
+        counts, ltot, bgc = ctx.count_bg(True)
+        ctx.mirror(W, counts)
+        bgprob = ctx.pattern_stats(W, True, 2, 2, ctx.bg_model(bgc, 2), ltot, counts)[0]
+        bgd = pk.DeviceArray.from_host(ctx, bgprob.to_host()[2])
+    pwms = np.maximum(rng.dirichlet(np.full(4, 0.5), size=(10 if W == 10 else 3 if W == 12 else 1, W)).astype(np.float32), np.float32(1e-20))
+    default = 4  # (pengk_internal.h: em_head_blocks)
+    ctx.set_option("em_fast", 2)
+    fetched = {}
+    try:
+        ctx.test_em_generation(0 if W < 14 else 1)
+        ref = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 2)
+        ctx.test_em_generation(2)
+        for K, skew in ((1, 0), (2, 0), (default, 0), (7, 3), (64, 0)) if W < 14 else ((1, 0), (64, 3)):
+            ctx.set_option("em_head_blocks", K)
+            ctx.set_option("em_test_skew", skew)
+            got = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 2)
+            fetched[K] = ctx.info("em_fetched_blocks")
+            assert got[0].tobytes() == ref[0].tobytes(), K
+            assert got[1].tolist() == ref[1].tolist() and got[2].tobytes() == ref[2].tobytes(), K
+        for bad in (0, 65):
+            with pytest.raises(Exception):
+                ctx.set_option("em_head_blocks", bad)
+    finally:
+        ctx.set_option("em_test_skew", 0)
+        ctx.set_option("em_head_blocks", default)
+        ctx.set_option("em_fast", 1)
+    if W < 14:
+        assert fetched[1] > fetched[2] > fetched[default], fetched
+    if W == 10:
+        assert fetched[64] == 0, fetched  # (64 blocks per cell: nothing left for the chains)
+
+
 def _ramp_counts(W, doublings=30, blocks_per_doubling=16):
     """A count table whose running sums cross a power of two about every `blocks_per_doubling` blocks of EVERY cell's
     chain (a block = 4096 terms of a cell = 16384 consecutive x), `doublings` times, then stay flat: several blocks
