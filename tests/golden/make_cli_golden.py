@@ -10,6 +10,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref", "peng_motif_ref")
 
+def wrapper_flags(w):
+    return ["-w", str(w), "-t", "10", "--count-threshold", "1", "--bg-model-order", "2", "--strand", "BOTH",
+            "--optimization_score", "MUTUAL_INFO", "--enrich_pseudocount_factor", "0.005", "-a", "10000.0", "--em-threshold", "0.08",
+            "--em-max-iterations", "100", "--max_merged_length", "14", "-b", "0.4", "--pseudo-counts", "10", "--threads", "1",
+            "--minimum-processed-patterns", "25", "--max-optimized-patterns", "50"]
+
+
 CASES = {
     # name: (fasta, extra args)
     "cli_mafk100_w8": ("MafK_100seqs.fasta", ["-w", "8"]),                          # BASELINE config 1
@@ -25,6 +32,12 @@ CASES = {
     # ever a seed; order 0 gives seeds, a hill-climb, PWMs and an EM over 16 patterns
     "cli_mafk_w2_bg0": ("MafK.fasta", ["-w", "2", "--bg-model-order", "0", "-t", "3", "--count-threshold", "1"]),
     "cli_mafk100_w2": ("MafK_100seqs.fasta", ["-w", "2"]),
+    # The command line the reference's Python wrapper builds (scripts/shoot_peng.py:122-153), every flag in its order with
+    # the WRAPPER's defaults -- which differ from the binary's (count threshold 1, 100 EM iterations, at least 25 processed
+    # patterns: scripts/shoot_peng.py:48,66,88 against src/Global.cpp:39,31,55): -w 6 on the 100-sequence set is the run
+    # of the reference's CI (.travis.yml:17-23), -w 10 on the full set the wrapper's own default.
+    "cli_wrapper_mafk100_w6": ("MafK_100seqs.fasta", wrapper_flags(6)),
+    "cli_wrapper_mafk_w10": ("MafK.fasta", wrapper_flags(10)),
 }
 
 

@@ -21,7 +21,9 @@ SELFTEST = os.path.join(HOST, "host_selftest")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 CASES = ["cli_mafk100_w8", "cli_mafk100_w6_plus_noem", "cli_mafk100_w8_logpval_nomerge", "cli_mafk_w10", "cli_mafk_w10_plus",
-         "cli_torture_w6", "cli_mafk100_w8_bg1_enrich", "cli_mafk_w10_bg0_nofilter", "cli_mafk_w2_bg0", "cli_mafk100_w2"]
+         "cli_torture_w6", "cli_mafk100_w8_bg1_enrich", "cli_mafk_w10_bg0_nofilter", "cli_mafk_w2_bg0", "cli_mafk100_w2",
+         # the command line of the reference's Python wrapper, with the wrapper's defaults (tests/golden/make_cli_golden.py)
+         "cli_wrapper_mafk100_w6", "cli_wrapper_mafk_w10"]
 
 
 def parse_meme(path):
@@ -86,6 +88,25 @@ def test_cli_matches_reference(tmp_path, name):
     em_ran = "--no-em" not in open(os.path.join(GOLD, "cli", name + ".args")).read()
     compare_outputs(meme, js, stdout, os.path.join(GOLD, "cli", name + ".meme"), os.path.join(GOLD, "cli", name + ".json"),
                     open(os.path.join(GOLD, "cli", name + ".stdout")).read(), em_ran)
+
+
+def test_cli_json_is_what_the_reference_wrapper_reads(tmp_path):
+    """The reference's Python wrapper (scripts/shoot_peng.py, out of scope) is bound to the binary by two things only: the
+    flag list it passes (:122-153 -- the cli_wrapper_* cases above run exactly that) and the JSON it loads and rewrites
+    (:197-200, 236-250, 260-295): top-level alphabet / alphabet_length / bg / patterns, per pattern iupac_motif,
+    pattern_length, sites, bg_prob, opt_bg_order, log(Pval), pwm (pattern_length rows of alphabet_length numbers).  A user
+    who points the wrapper's PENG at this binary finds every key with the type the wrapper's writers format."""
+    meme, js, stdout = run_cli(tmp_path, "cli_wrapper_mafk_w10")
+    d = json.load(open(js))
+    assert set(d) == {"alphabet", "alphabet_length", "bg", "patterns"}
+    assert d["alphabet"] == "ACGT" and d["alphabet_length"] == 4 and len(d["bg"]) == 4 and len(d["patterns"]) > 0
+    for p in d["patterns"]:
+        assert set(p) == {"iupac_motif", "pattern_length", "sites", "log(Pval)", "bg_prob", "opt_bg_order", "pwm"}
+        assert isinstance(p["iupac_motif"], str) and len(p["iupac_motif"]) == p["pattern_length"]
+        assert isinstance(p["sites"], int) and isinstance(p["opt_bg_order"], int)
+        assert isinstance(p["log(Pval)"], (int, float)) and isinstance(p["bg_prob"], (int, float))  # (an underflown bg_prob prints as 0, as the reference's does)
+        assert len(p["pwm"]) == p["pattern_length"] and all(len(row) == 4 for row in p["pwm"])
+        assert all(abs(sum(row) - 1.0) < 1e-5 for row in p["pwm"])
 
 
 @pytest.mark.parametrize("mode", ["0", "1"])
