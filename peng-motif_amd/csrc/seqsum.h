@@ -259,7 +259,8 @@ __device__ __forceinline__ float fold_block(const Row& mine, uint32_t lane, floa
 // power of two, the sum about to cross one) or whose test fails is evaluated by fold_block as before.  Exactness never
 // rests on the estimate: it only decides which blocks take the short way.
 constexpr uint32_t NO_BINADE = 0xFFFFFFFFu;
-// record of a chain's block 0 that was folded ahead of the chain (its start is known exactly: zero): d0 = the sum behind it
+// record of a chain's block 0 when the chain's first blocks were folded ahead of it (the start is known exactly: zero):
+// d0 = the sum behind them, pad = how many (1..64; their own records hold nothing)
 constexpr uint32_t SUM_BEHIND = 0xFFFFFFFEu;
 // exponent field of the binade of s as bases_of sees it: zero, denormals and the lowest normal binade are one
 __device__ __forceinline__ uint32_t binade_of(float s) {

@@ -935,8 +935,8 @@ def test_em_blocks_ahead_at_w12_against_the_oracle_on_tables_that_cross_many_bin
         assert got[i].tobytes() == ref.astype(np.float32).tobytes(), (kind, skew, i)
         assert np.float32(change[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
     chains = len(pwms) * 4 * W * 2
-    # (block 0 of a chain is folded from zero beside the block evaluation and not counted; on these tables every chain
-    # still meets blocks in which its sum passes a power of two)
+    # (the first em_head_blocks = 4 blocks of a chain are folded from zero beside the block evaluation and not counted; on
+    # these tables every chain still meets blocks behind them in which its sum passes a power of two)
     assert met["fetched_blocks"] >= chains, met
     if kind == "ramp":
         assert met["fetched_blocks"] > 10 * chains, met  # ~30 crossings per chain
