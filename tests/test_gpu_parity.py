@@ -897,6 +897,49 @@ def test_em_head_blocks_folded_beside_the_evaluation(ctx, W):
         assert fetched[64] == 0, fetched  # (64 blocks per cell: nothing left for the chains)
 
 
+@pytest.mark.parametrize("W,n", [(10, 1), (10, 9), (10, 40), (12, 9)])
+def test_em_serial_iteration_protocol_at_its_edges(ctx, W, n):
+    """The blocks-ahead scheme keeps the finalize step of iteration k at the head of iteration k + 1's first kernel, flags
+    and PWMs double-buffered by iteration parity, the last one in em_serial_finish_kernel (csrc/em.hip).  Its edges: 0, 1, 2
+    and 11 iterations; thresholds that stop nobody, some PWMs early, PWMs after one iteration, everybody before the first; one PWM, a partial
+    group of eight, several batches (table budget 20 MiB = 5 PWMs); and the same call twice on one context (no flag may
+    survive a call).  Against the dependent-addition fold: PWMs, iteration counts and `change` bit for bit."""
+    NP = 4 ** W
+    rng = np.random.default_rng(1000 * W + n)
+    c = rng.poisson(2.0, NP).astype(np.uint32)
+    bg = (rng.dirichlet(np.ones(64), size=NP // 64).reshape(-1)).astype(np.float32)
+    counts, bgd = pk.DeviceArray.from_host(ctx, c), pk.DeviceArray.from_host(ctx, bg)
+    pw = rng.dirichlet(np.ones(4) * 2, size=(n, W)).astype(np.float32)
+    pw[0] = np.float32(0.25)
+    seen = set()
+    ctx.set_option("em_fast", 2)
+    try:
+        for max_it in ((0, 1, 2, 11) if W == 10 else (0, 1, 3)):
+            for thr in (0.0, 0.05, W - 0.5, 1e9):
+                for budget in ((0, 20) if n == 40 else (0,)):
+                    ctx.set_option("em_table_budget_mb", budget)
+                    ctx.test_em_generation(0)
+                    ref = ctx.em(W, pw, counts, bgd, 1e4, thr, max_it)
+                    ctx.test_em_generation(2)
+                    for again in range(2):
+                        got = ctx.em(W, pw, counts, bgd, 1e4, thr, max_it)
+                        assert got[1].tolist() == ref[1].tolist(), (max_it, thr, budget, again)
+                        assert got[0].tobytes() == ref[0].tobytes() and got[2].tobytes() == ref[2].tobytes(), (max_it, thr, budget, again)
+                    seen.update(ref[1].tolist())
+                    if max_it == 0:
+                        assert ref[0].tobytes() == pw.tobytes() and set(ref[1].tolist()) == {0}
+                    if thr == 1e9:  # (the loop starts from change = W, src/peng.cpp:101-106: nothing runs)
+                        assert ref[0].tobytes() == pw.tobytes() and set(ref[1].tolist()) == {0}
+                    if thr == W - 0.5 and max_it > 0:
+                        assert min(ref[1].tolist()) == 1
+    finally:
+        ctx.set_option("em_table_budget_mb", 0)
+        ctx.test_em_generation(2)
+        ctx.set_option("em_fast", 1)
+    if n >= 9 and W == 10:
+        assert len(seen) >= 5, seen  # PWMs leave at different iterations
+
+
 def _ramp_counts(W, doublings=30, blocks_per_doubling=16):
     """A count table whose running sums cross a power of two about every `blocks_per_doubling` blocks of EVERY cell's
     chain (a block = 4096 terms of a cell = 16384 consecutive x), `doublings` times, then stay flat: several blocks
