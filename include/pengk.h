@@ -74,7 +74,7 @@ int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
  * histograms (W = 8 .. 14); "n_windows_hint" = total windows of the attached items (sizes the key buffer
  * tightly; set it after pengk_set_sequences); "key_cap_override" (test hook) entries per bucket region of the
  * partitioned count, 0 = automatic; "iupac_group_bytes" (test hook) scratch budget for one group of large
- * patterns in pengk_iupac_aggregate, 0 = 1 GiB; "em_fast" 1 (default) / 0 / 2, see pengk_em.  Info: "deferred_items" (of the last pengk_count;
+ * patterns in pengk_iupac_aggregate, 0 = 1 GiB; "em_fast" 2 (default) / 1 / 0, see pengk_em.  Info: "deferred_items" (of the last pengk_count;
  * synchronises), "num_cu"; of the last pengk_em / pengk_em_device call in the serial mode with its blocks evaluated ahead
  * (synchronise): "em_fetched_blocks" (blocks a chain added term by term), "em_mispredicted_blocks" (of those: blocks
  * whose estimated binade did not hold), "em_restaged_blocks" / "em_restaged_waits" (csrc/seqsum.h, WalkCounts). */
@@ -238,7 +238,7 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  *      src/peng.cpp:48-197; row normalisation src/iupac_pattern.cpp:291-303) ----------------------
  * h_pwms: n_pwm x W x 4 floats, updated in place with the PWM the reference's loop ends on (before the
  * extra normalisation of the IUPACPattern(ori, pwm) constructor).  Three modes (option "em_fast"):
- *   2  serial: the reference's float32 arithmetic including the ORDER in which it adds the 4^W weights of a PWM
+ *   2  (library default) serial: the reference's float32 arithmetic including the ORDER in which it adds the 4^W weights of a PWM
  *      cell (src/peng.cpp:121-127) -- PWMs, iteration counts and `change` are the reference's bit for bit.  From
  *      W = 8 on a cell's chain of roundings is evaluated as a scan (csrc/seqsum.h; a PWM with a negative or non-finite
  *      weight is summed by a plain loop).  What a caller needs when discrete decisions follow (motif merging compares
@@ -265,7 +265,7 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  *                              batch writes is still in the 256 MiB Infinity Cache when it is read), above that a
  *                              quarter of the free memory, at most 24 GiB.
  *   0  the reference's float32 terms (three divisions per k-mer weight), summed in fp64 through a fixed tree.
- *   1  (library default) the weight c*s / (1 + s/(prod/bg)) evaluated as c*s*prod / (prod + s*bg) with one
+ *   1  (opt-in) the weight c*s / (1 + s/(prod/bg)) evaluated as c*s*prod / (prod + s*bg) with one
  *      reciprocal (~1 ulp per term), fp64 tree sums: the throughput mode, 2.3e12 PWM-k-mer evaluations/s.
  * Modes 0 and 1 agree with the reference within BASELINE.json's 1e-5 relative (the reference's own serial float32
  * sums are off by up to 2.6e-4 relative from the exact ones); the float32 product over the PWM columns is built in

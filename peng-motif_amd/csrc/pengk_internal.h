@@ -56,7 +56,7 @@ struct pengk_ctx {
                                 // (W >= 10; else as 1), 1 = the scan, block after block, 0 = dependent additions
   int em_head_blocks = 4;       // K5 serial mode, W >= 10: the first blocks of every cell folded from zero beside the evaluation of the others
   int em_lean_div = 1;          // K5 serial mode: the weights' divisions without range scaling where a PWM's operand ranges allow (em.hip, lean_div)
-  int em_fast = 1;              // K5: 1 = one reciprocal per k-mer weight (default), 0 = the reference's three divisions
+  int em_fast = 2;              // K5: 2 = the reference's serial float32 sums, bit-exact (default); 1 = one reciprocal per k-mer weight, 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms
   int scatter_blocks_per_cu = 0; // tuning hook: workgroups per CU of the partitioned scan (0 = default)
   void* d_sim = nullptr;         // motif similarity grid: PWMs | complements | lengths | sites | scores

@@ -106,7 +106,19 @@ def test_mirror_sweep_and_em_are_deterministic(ctx):
         for q in range(W):
             pw[i, q, ((top + 977 * i) >> (2 * q)) & 3] = 0.7
     bg2 = pk.DeviceArray.from_host(ctx, bgp[2])
-    r1, it1, _ = ctx.em(W, pw, counts, bg2, 1e4, 0.08, 10)
-    r2, it2, _ = ctx.em(W, pw, counts, bg2, 1e4, 0.08, 10)
-    assert r1.tobytes() == r2.tobytes() and np.array_equal(it1, it2)
-    assert np.allclose(r1.sum(axis=2), 1.0, atol=1e-6)
+    got = {}
+    try:
+        for mode in (2, 1):  # the library's default (serial float32 sums, bit-exact) and the throughput mode (fixed-order fp64 tree)
+            ctx.set_option("em_fast", mode)
+            r1, it1, _ = ctx.em(W, pw, counts, bg2, 1e4, 0.08, 10)
+            r2, it2, _ = ctx.em(W, pw, counts, bg2, 1e4, 0.08, 10)
+            assert r1.tobytes() == r2.tobytes() and np.array_equal(it1, it2)
+            assert np.allclose(r1.sum(axis=2), 1.0, atol=1e-6)
+            got[mode] = (r1, it1)
+    finally:
+        ctx.set_option("em_fast", 2)
+    # (the two modes may stop a PWM one iteration apart when `change` lands next to the threshold -- why the bit-exact mode
+    # is the default; where they ran the same number of iterations the PWMs agree to the float32 sums' own error)
+    same = got[1][1] == got[2][1]
+    assert same.sum() >= 6 and np.abs(got[1][1] - got[2][1]).max() <= 1
+    assert np.abs(got[1][0][same].astype(np.float64) - got[2][0][same]).max() <= 3e-3

@@ -23,6 +23,9 @@ CASES = ["mafk100_w8_both", "mafk100_w8_plus", "mafk100_w6_both", "torture_w6_bo
 @pytest.fixture(scope="module")
 def ctx():
     c = pk.Context(0)
+    # (this module's tests name the EM mode they run and put 1 back: the throughput mode is their base state; the
+    # library's own default is 2, the bit-exact mode -- test_library_default_em_mode_is_the_bit_exact_one)
+    c.set_option("em_fast", 1)
     yield c
     c.close()
 
@@ -461,6 +464,29 @@ def test_iupac_aggregation_bit_exact(ctx, golden_dir, name):
     fb = g["iupac_fbits"]
     for j, f in enumerate(["bg_p", "expected", "zscore", "log_pvalue"]):
         assert np.array_equal(out[f].view(np.uint32), fb[:, j]), f
+
+
+def test_library_default_em_mode_is_the_bit_exact_one(golden_dir):
+    """A context nobody set an option on runs pengk_em in the serial mode: the compiled reference's PWMs (golden pwm_post
+    is what the reference holds after its constructor's extra normalisation), iteration counts and the oracle's
+    float32 `change`, bit for bit -- a caller that binds the ABI gets the reference's results without asking."""
+    r = cpu_pipeline(golden_dir, "mafk_w10_both")
+    g, W, K = r["g"], r["W"], r["K"]
+    c = pk.Context(0)
+    try:
+        d = gpu_tables(c, r)
+        bg_k = pk.DeviceArray.from_host(c, d["bgprob"].to_host()[K])
+        pw, iters, change = c.em(W, g["pwm_pre"], d["counts"], bg_k, 1e4, 0.08, 10)
+    finally:
+        c.close()
+    assert len(g["pwm_ids"]) > 0
+    for i in range(len(g["pwm_ids"])):
+        ref, it, ch = po.em(W, r["counts"], r["bgp"][K], g["pwm_pre"][i], 1e4, 0.08, 10, mode=0, final_norm=False)
+        assert iters[i] == it == int(g["em_iters"][i])
+        assert pw[i].tobytes() == ref.astype(np.float32).tobytes()
+        assert np.float32(change[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
+        fin = pw[i] / pw[i].sum(axis=1, keepdims=True, dtype=np.float32)
+        assert bits_equal(fin.astype(np.float32), g["pwm_post"][i].astype(np.float32))
 
 
 @pytest.mark.parametrize("name", ["mafk100_w8_both", "mafk100_w8_plus", "torture_w6_plus", "mafk_w10_both", "mafk_w10_plus"])
