@@ -252,9 +252,9 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  *                              keeps a span's weights in LDS (half the table traffic at W = 12; measured no faster).
  *        "em_overlap"          W >= 10: streams the batches of PWMs take turns on, 1..4 (default 2; the
  *                              context's own stream waits for the others before the call returns or copies).
- *        "em_head_blocks"      W >= 10, 1..64 (default 4): the first blocks of every cell -- where the sum doubles from
+ *        "em_head_blocks"      W >= 10, 1..64 (default 1): the first blocks of every cell -- where the sum doubles from
  *                              block to block -- are folded from zero beside the evaluation of the others, the chain
- *                              starts behind them.  Results do not depend on it.
+ *                              starts behind them.  Results do not depend on it (and more than block 0 measured no faster).
  *        "em_test_skew"        (test hook) n > 0: about every n-th block gets a WRONG binade estimate -- results must not
  *                              change, only the time (the estimate never carries exactness).  0 = off.
  *        "em_test_lookback"    (test hook, "em_serial_scan" = 3) n > 0: every n-th workgroup acts as if the look-back for

@@ -852,28 +852,35 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
     // to block there (1 -> 2 -> 4 blocks' worth), so these are the blocks a chain would take the long way, several
     // evaluations each; here they cost nothing on the iteration's critical path as long as these workgroups end before the
     // spans' do.  A block is asked for as soon as the one before it has left the buffer for the registers.
+    // (ONE place that holds a Row and calls fold_block: a second instantiation costs ~30 registers and with them the
+    // fourth wave per SIMD of every workgroup of this kernel -- the spans' included: 16 PWMs 0.77 -> 0.83 ms, W = 12 10.0 -> 12.7)
     seqsum::Row mine;
     seqsum::Stats st;
     float s0 = 0.0f;
-    auto head = [&](const auto& src) {
-      src.stage(0u, lane, buf);
-#pragma unroll 1
-      for (uint32_t b = 0; b < head_blocks; ++b) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        mine.read_staged(buf, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (b + 1u < head_blocks) src.stage(b + 1u, lane, buf);
-        s0 = seqsum::fold_block(mine, lane, s0, st);
+    const bool first_position = (cell >> 2) == 0u;  // (wave-uniform)
+    auto stage = [&](uint32_t b) {
+      // (the sources' per-lane offsets are worked out again for every block -- from a lane number the compiler cannot
+      // see through -- so that they are not sixteen more registers alive across fold_block)
+      uint32_t l = lane;
+      asm volatile("" : "+v"(l));
+      if (first_position) {
+        EmTerms0<W> src0{w, cell & 3u};
+        src0.bind_stage(l);
+        src0.stage(b, l, buf);
+      } else {
+        EmTerms<W> src{w, cell >> 2, cell & 3u};
+        src.bind_stage(l);
+        src.stage(b, l, buf);
       }
     };
-    if ((cell >> 2) == 0u) {
-      EmTerms0<W> src0{w, cell & 3u};
-      src0.bind_stage(lane);
-      head(src0);
-    } else {
-      EmTerms<W> src{w, cell >> 2, cell & 3u};
-      src.bind_stage(lane);
-      head(src);
+    stage(0u);
+#pragma unroll 1
+    for (uint32_t b = 0; b < head_blocks; ++b) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      mine.read_staged(buf, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (b + 1u < head_blocks) stage(b + 1u);
+      s0 = seqsum::fold_block(mine, lane, s0, st);
     }
     if (lane == 0) {
       seqsum::BlockRecord out;

@@ -54,7 +54,8 @@ struct pengk_ctx {
   int em_serial_scan = 2;       // K5 serial mode: cells summed by 3 = the scan of seqsum.h with its blocks evaluated ahead of the
                                 // chain, two launches per iteration (W = 10, 12; else as 2), 2 = the same as three launches
                                 // (W >= 10; else as 1), 1 = the scan, block after block, 0 = dependent additions
-  int em_head_blocks = 4;       // K5 serial mode, W >= 10: the first blocks of every cell folded from zero beside the evaluation of the others
+  int em_head_blocks = 1;       // K5 serial mode, W >= 10: the first blocks of every cell folded from zero beside the evaluation of the others
+                                // (1 = block 0 only: more measured level at 16 PWMs, slower at 2 and at 1000, profiles/r05_em_kernels.log)
   int em_lean_div = 1;          // K5 serial mode: the weights' divisions without range scaling where a PWM's operand ranges allow (em.hip, lean_div)
   int em_fast = 2;              // K5: 2 = the reference's serial float32 sums, bit-exact (default); 1 = one reciprocal per k-mer weight, 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms

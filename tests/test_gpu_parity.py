@@ -881,7 +881,7 @@ def test_em_serial_blocks_ahead_with_wrong_binade_estimates(ctx, W, skew, scheme
 def test_em_head_blocks_folded_beside_the_evaluation(ctx, W):
     """Option em_head_blocks = K: the first K blocks of every cell are folded one after the other from zero by extra
     workgroups of em_span_eval_kernel (record 0 carries the sum and K, the chain starts behind them; csrc/seqsum.h
-    walk_chain).  K = 1 (round 4's layout), 2, the default, 7 and 64 (a whole 64-block chunk: at W = 10 the whole cell)
+    walk_chain).  K = 1 (the default), 2, 4, 7 and 64 (a whole 64-block chunk: at W = 10 the whole cell)
     give the dependent-addition fold's bits, also with wrong binade estimates; fewer blocks are left to the chains."""
     NP = 4 ** W
     rng = np.random.default_rng(7 * W)
@@ -896,14 +896,14 @@ def test_em_head_blocks_folded_beside_the_evaluation(ctx, W):
         bgprob = ctx.pattern_stats(W, True, 2, 2, ctx.bg_model(bgc, 2), ltot, counts)[0]
         bgd = pk.DeviceArray.from_host(ctx, bgprob.to_host()[2])
     pwms = np.maximum(rng.dirichlet(np.full(4, 0.5), size=(10 if W == 10 else 3 if W == 12 else 1, W)).astype(np.float32), np.float32(1e-20))
-    default = 4  # (pengk_internal.h: em_head_blocks)
+    default = 1  # (pengk_internal.h: em_head_blocks)
     ctx.set_option("em_fast", 2)
     fetched = {}
     try:
         ctx.test_em_generation(0 if W < 14 else 1)
         ref = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 2)
         ctx.test_em_generation(2)
-        for K, skew in ((1, 0), (2, 0), (default, 0), (7, 3), (64, 0)) if W < 14 else ((1, 0), (64, 3)):
+        for K, skew in ((1, 0), (2, 0), (4, 0), (7, 3), (64, 0)) if W < 14 else ((1, 0), (64, 3)):
             ctx.set_option("em_head_blocks", K)
             ctx.set_option("em_test_skew", skew)
             got = ctx.em(W, pwms, counts, bgd, 1e4, 0.0, 2)
@@ -918,7 +918,7 @@ def test_em_head_blocks_folded_beside_the_evaluation(ctx, W):
         ctx.set_option("em_head_blocks", default)
         ctx.set_option("em_fast", 1)
     if W < 14:
-        assert fetched[1] > fetched[2] > fetched[default], fetched
+        assert fetched[1] > fetched[2] > fetched[4], fetched
     if W == 10:
         assert fetched[64] == 0, fetched  # (64 blocks per cell: nothing left for the chains)
 
@@ -1004,8 +1004,8 @@ def test_em_blocks_ahead_at_w12_against_the_oracle_on_tables_that_cross_many_bin
         assert got[i].tobytes() == ref.astype(np.float32).tobytes(), (kind, skew, i)
         assert np.float32(change[i]).view(np.uint32) == np.float32(ch).view(np.uint32)
     chains = len(pwms) * 4 * W * 2
-    # (the first em_head_blocks = 4 blocks of a chain are folded from zero beside the block evaluation and not counted; on
-    # these tables every chain still meets blocks behind them in which its sum passes a power of two)
+    # (block 0 of a chain is folded from zero beside the block evaluation and not counted; on these tables every chain
+    # still meets blocks behind it in which its sum passes a power of two)
     assert met["fetched_blocks"] >= chains, met
     if kind == "ramp":
         assert met["fetched_blocks"] > 10 * chains, met  # ~30 crossings per chain
