@@ -45,6 +45,7 @@ while time.time() < t_end:
     out = {}
     skew = int(rng.choice([0, 0, 1, 3, 17]))   # test hook: wrong binade estimates for every skew-th block (mode 2 only)
     lookback = int(rng.choice([0, 0, 1, 5]))
+    ctx.set_option("em_head_blocks", int(rng.choice([1, 1, 2, 4, 9])))  # (blocks folded from zero beside the evaluation: scheme 2)
     for scan in (3, 2, 1, 0):
         ctx.test_em_generation(scan)
         ctx.set_option("em_test_skew", skew if scan >= 2 else 0)
@@ -53,6 +54,7 @@ while time.time() < t_end:
     ctx.test_em_generation(2)
     ctx.set_option("em_test_skew", 0)
     ctx.set_option("em_test_lookback", 0)
+    ctx.set_option("em_head_blocks", 1)
     bad_modes = [k for k in (1, 2, 3) if not (out[k][0].tobytes() == out[0][0].tobytes() and out[k][1].tolist() == out[0][1].tolist()
                                            and out[k][2].tobytes() == out[0][2].tobytes())]
     if bad_modes:
