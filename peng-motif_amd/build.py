@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("PENGK_BUILD_OUT") or os.path.join(HERE, "libpengk.so")  # PENGK_BUILD_OUT: variant builds for tools/ab.sh
-SOURCES = ["api.hip", "count.hip", "stats.hip", "iupac.hip", "em.hip", "em_legacy.hip", "similarity.hip", "seqsum.hip", "comm.hip", "pack.cpp"]
-HEADERS = [os.path.join(CSRC, "pengk_internal.h"), os.path.join(CSRC, "em_common.h"), os.path.join(CSRC, "seqsum.h"), os.path.join(ROOT, "include", "pengk.h")]
+SOURCES = ["api.hip", "count.hip", "stats.hip", "iupac.hip", "em.hip", "em_fused.hip", "em_legacy.hip", "similarity.hip", "seqsum.hip", "comm.hip", "pack.cpp"]
+HEADERS = [os.path.join(CSRC, "pengk_internal.h"), os.path.join(CSRC, "em_common.h"), os.path.join(CSRC, "em_serial.h"), os.path.join(CSRC, "seqsum.h"), os.path.join(ROOT, "include", "pengk.h")]
 # -ffp-contract=off: float32 arithmetic must round exactly like the reference's scalar x86 code.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]

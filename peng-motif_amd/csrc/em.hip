@@ -15,7 +15,7 @@
 // reference adds them serially in float32 (error up to 2.6e-4 relative at W=10);
 // here they are accumulated in fp64 through a fixed tree (thread -> wave -> block -> grid), so the
 // result is deterministic and within 1 ulp(float) of the exact sum.
-#include "em_common.h"
+#include "em_serial.h"
 
 namespace pengk {
 namespace {
@@ -316,118 +316,7 @@ __global__ __launch_bounds__(256) void em_accumulate_kernel(const float* __restr
 // reverse-complement twins, so the last bits of those sums decide what the program prints.  A cell's sum is inherently
 // sequential as written, but its chain of roundings has structure a wave can use (seqsum.h).
 //
-// ---- the scan with its blocks evaluated ahead of the chain (seqsum.h, "blocks ahead of their chain"; W >= 10) ----------
-// Per iteration and PWM (three launches, nothing between them but the kernel boundaries):
-//   em_weights_span_kernel   at its head the PREVIOUS iteration's finalize step -- row normalisation, change, "still
-//                            running" (fused_head: every workgroup of a PWM repeats the 4 W divisions from the cell sums
-//                            the chains stored; no arrival protocol at a chain's end, no finalize launch) --, then
-//                            the weights, span by span, and with them the plain sum of every block of every cell;
-//   (em_block_predict_kernel their prefix per cell = an estimate of the sum in front of each block; a block whose estimate
-//                            stays clear of a power of two from its first to its last term gets that binade -- for cells of
-//                            up to 1024 blocks the next kernel does that itself)
-//   em_span_eval_kernel      every block with a binade gets its two increments (block_increments) -- all blocks of all
-//                            cells at once, a workgroup per span of the table, instead of one after the other per cell;
-//   em_chain_store_kernel    one wave per cell walks the blocks: one addition per evaluated block, fold_block for the
-//                            others (the few where the sum crosses a power of two), and stores the cell's sum;
-//   (em_serial_finish_kernel once per call: the last iteration's finalize step, every PWM's matrix into the caller's array).
-// Option em_serial_scan = 3 (W = 10, 12) runs the first two as ONE kernel, em_span_fused_kernel, below.
-// A span = 16384 consecutive x = 4^7: for a position p <= 6 a span holds block `span` of each of the four cells (p, a);
-// for p >= 7 it holds four consecutive blocks of the one cell (p, digit p of the span).
-template <int W>
-struct BlockGeo {
-  static_assert(W >= 8, "a span is 4^7 x");
-  static constexpr uint32_t NP = 1u << (2 * W);
-  static constexpr uint32_t SPANS = NP >> 14;
-  static constexpr uint32_t NBLK = (1u << (2 * W - 2)) / seqsum::BLOCK;  // per cell (= SPANS)
-  static constexpr uint32_t CELLS = 4u * W;
-  // cells of up to 1024 blocks: the evaluating wave adds up the cell's block sums itself; longer ones (W = 14) get their
-  // prefix from em_block_predict_kernel
-  static constexpr bool PREDICT_IN_EVAL = NBLK <= 1024u;
-  // the block of cell (p, a) that quarter q of span sp belongs to (p >= 7), and the cell's a
-  static __device__ __forceinline__ uint32_t high_block(uint32_t p, uint32_t sp, uint32_t q) {
-    const uint32_t sh = 2u * (p - 7u);
-    return 4u * (((sp >> (sh + 2u)) << sh) | (sp & ((1u << sh) - 1u))) + q;
-  }
-  static __device__ __forceinline__ uint32_t high_digit(uint32_t p, uint32_t sp) { return (sp >> (2u * (p - 7u))) & 3u; }
-};
-
-// The binade of a block from the estimates of the sum in front of it and behind it, or NO_BINADE when the two -- widened
-// by 2^-9, far more than a float32 chain of 4^13 terms drifts from the exact sum in practice -- do not share one.  A wrong
-// guess costs time, never the result (seqsum.h).
-__device__ __forceinline__ uint32_t block_binade(double before, double after, uint32_t skew = 0u, uint32_t key = 0u) {
-  const float lo = (float)(before * (1.0 - 1.0 / 512.0)), hi = (float)(after * (1.0 + 1.0 / 512.0));
-  const bool sane = lo >= 0.0f && hi < __uint_as_float(0x7F000000u);
-  uint32_t e = sane && seqsum::binade_of(lo) == seqsum::binade_of(hi) ? seqsum::binade_of(lo) : seqsum::NO_BINADE;
-  // Test hook (option "em_test_skew" = n > 0): about every n-th block gets a WRONG answer -- the binade above the
-  // right one, or a binade where there is none to be had -- so that the suite exercises what a bad estimate costs
-  // (the chain's checks, its fetches on demand) far more often than real inputs do.  Results must not change.
-  if (skew != 0u && sane && ((key * 2654435761u) >> 16) % skew == 0u) {
-    if (e == seqsum::NO_BINADE) e = seqsum::binade_of(lo);
-    else if (e < 200u) e += 1u;
-  }
-  return e;
-}
-
-// ---- the three IEEE divisions of a weight, without the range scaling when it cannot matter ---------------------------
-// `a / b` in float compiles to v_div_scale x 2, v_rcp, five fma / mul, v_div_fmas, v_div_fixup (11 instructions, the
-// reciprocal at quarter rate): 33 of the ~47 vector instructions of a weight.  v_div_scale returns its operand unchanged
-// and VCC = 0 -- so that v_div_fmas is a plain fma -- and v_div_fixup passes the quotient through, when (gfx9 ISA,
-// V_DIV_SCALE_F32 / V_DIV_FIXUP_F32): numerator and denominator are finite, the denominator is normal and below 2^126,
-// the numerator's biased exponent is above 23 (or the numerator is zero: every product below is then zero, and so is the
-// fixup's answer), the exponents differ by less than 96 and the quotient is normal.  Then the eight instructions in
-// between ARE the division, bit for bit: the same v_rcp_f32, the same fmas in the same order.  lean_div issues exactly
-// those.  Whether a workgroup may use it is decided once per workgroup from the RANGES its operands can take --
-// the PWM's columns give the range of the product, em_bg_range_kernel the range of the background table, the count
-// table's 32 bits the range of c * s -- with a factor of two of slack on every derived bound (lean_ranges_ok);
-// a workgroup whose ranges do not qualify (tiny PWM entries, a degenerate background) runs the plain divisions.
-__device__ __forceinline__ float lean_div(float a, float b) {
-  const float y0 = __builtin_amdgcn_rcpf(b);
-  const float e0 = __builtin_fmaf(-b, y0, 1.0f);
-  const float y1 = __builtin_fmaf(e0, y0, y0);
-  const float q0 = a * y1;
-  const float r0 = __builtin_fmaf(-b, q0, a);
-  const float q1 = __builtin_fmaf(r0, y1, q0);
-  const float r1 = __builtin_fmaf(-b, q1, a);
-  return __builtin_fmaf(r1, y1, q1);
-}
-template <bool LEAN>
-__device__ __forceinline__ float em_div(float a, float b) {
-  if constexpr (LEAN) return lean_div(a, b);
-  else return a / b;
-}
-// a / b for every a in [a_lo, a_hi] (or a == 0) and b in [b_lo, b_hi], all bounds positive: is the unscaled sequence the
-// division?  (biased exponents; the quotient of a and b lies in [2^(Ea - Eb - 1), 2^(Ea - Eb + 1)))
-__device__ __forceinline__ bool lean_div_ok(float a_lo, float a_hi, float b_lo, float b_hi) {
-  auto fin = [](float x) { return __float_as_uint(x) - 0x00800000u < 0x7F000000u; };  // normal, finite, positive
-  if (!(fin(a_lo) && fin(a_hi) && fin(b_lo) && fin(b_hi)) || a_lo > a_hi || b_lo > b_hi) return false;
-  const int ea_lo = (int)(__float_as_uint(a_lo) >> 23), ea_hi = (int)(__float_as_uint(a_hi) >> 23);
-  const int eb_lo = (int)(__float_as_uint(b_lo) >> 23), eb_hi = (int)(__float_as_uint(b_hi) >> 23);
-  return eb_hi <= 251 && ea_lo >= 25 && ea_hi - eb_lo <= 94 && ea_lo - eb_hi >= -123;
-}
-// The ranges of one PWM's three divisions (src/peng.cpp:124-125, 180-197): odds = pr / bg, t = s / odds,
-// w = (c s) / (1 + t).  bg_range = {min, max} of the background table as float bits (em_bg_range_kernel).
-template <int W>
-__device__ __forceinline__ bool lean_ranges_ok(const float* s_pwm, uint32_t bg_lo_bits, uint32_t bg_hi_bits, float saturation) {
-  float p_lo = 1.0f, p_hi = 1.0f;
-  for (int p = 0; p < W; ++p) {
-    const float a = s_pwm[p * 4], b = s_pwm[p * 4 + 1], c = s_pwm[p * 4 + 2], d = s_pwm[p * 4 + 3];
-    if (!(a > 0.0f && b > 0.0f && c > 0.0f && d > 0.0f)) return false;
-    p_lo *= fminf(fminf(a, b), fminf(c, d));
-    p_hi *= fmaxf(fmaxf(a, b), fmaxf(c, d));
-  }
-  // (products round: half a unit in the last place per factor, far inside the factor of two below)
-  p_lo *= 0.5f;
-  p_hi *= 2.0f;
-  const float b_lo = __uint_as_float(bg_lo_bits), b_hi = __uint_as_float(bg_hi_bits);
-  if (bg_hi_bits > 0x7F7FFFFFu || !(saturation > 0.0f)) return false;  // a negative or non-finite background entry
-  if (!lean_div_ok(p_lo, p_hi, b_lo, b_hi)) return false;
-  const float o_lo = p_lo / b_hi * 0.5f, o_hi = p_hi / b_lo * 2.0f;  // odds
-  if (!lean_div_ok(saturation, saturation, o_lo, o_hi)) return false;
-  const float t_hi = saturation / o_lo * 2.0f;  // s / odds <= t_hi; 1 + t in [1, 2 (1 + t_hi)]
-  const float n_lo = saturation * 0.5f, n_hi = saturation * 8589934592.0f;  // c s, c in [1, 2^32): [s / 2, 2^33 s]
-  return lean_div_ok(n_lo, n_hi, 1.0f, (1.0f + t_hi) * 2.0f);
-}
-
+// (the scheme's shared pieces -- span geometry, binade estimate, lean division, finalize step, LDS layout: em_serial.h)
 // {min, max} of the background table as float bits (non-negative floats order like their bits; a negative entry or a NaN
 // has the sign or all exponent bits set and ends up as a "max" no range test accepts).  Once per pengk_em call.
 __global__ __launch_bounds__(1024) void em_bg_range_kernel(const float* __restrict__ bg, uint32_t np, uint32_t* __restrict__ range) {
@@ -500,111 +389,6 @@ __global__ __launch_bounds__(256) void em_div_check_kernel(unsigned long long se
   atomicAdd(out, checked);
   atomicAdd(out + 1, bad);
   atomicAdd(out + 2, zero);
-}
-
-// What F_j, the finalize step of iteration j, makes of a PWM: the reference's float32 epilogue -- normalise rows
-// (src/peng.cpp:129, src/iupac_pattern.cpp:291-303), change = sum |new - old| in p-major order (:132-137) -- from the cell
-// sums in s_new[0 .. 4 W) and the previous PWM in s_old[0 .. 4 W) (LDS; every thread of the workgroup calls it between
-// two barriers of its own).  The new PWM is left in s_new, the cells' |new - old| in s_old; returns `change` (the same
-// value in every thread: each adds up the 4 W differences itself, in p-major order, from 16-byte LDS reads).
-template <int W>
-__device__ __forceinline__ float finalize_rows(float* s_new, float* s_old, uint32_t t) {
-  typedef seqsum::f4 f4;
-  float mine = 0.0f, diff = 0.0f;
-  if (t < 4u * W) {
-    const f4 row = reinterpret_cast<const f4*>(s_new)[t >> 2];
-    float sum = 0.0f;
-    sum += row.x;
-    sum += row.y;
-    sum += row.z;
-    sum += row.w;
-    mine = s_new[t] / sum;
-    diff = fabsf(mine - s_old[t]);
-  }
-  __syncthreads();
-  if (t < 4u * W) {
-    s_new[t] = mine;
-    s_old[t] = diff;
-  }
-  __syncthreads();
-  float change = 0.0f;
-  f4 d[W];
-#pragma unroll
-  for (int p = 0; p < W; ++p) d[p] = reinterpret_cast<const f4*>(s_old)[p];
-#pragma unroll
-  for (int p = 0; p < W; ++p) {
-    change += d[p].x;
-    change += d[p].y;
-    change += d[p].z;
-    change += d[p].w;
-  }
-  return change;
-}
-
-// The pieces of the per-PWM state the two-launch scheme keeps beside the caller's arrays (all indexed by PWM):
-//   run[2][n]     run[j & 1] = "still running" behind F_j; launch k reads run[k & 1] (= behind F_(k-2)) and writes
-//                 run[(k - 1) & 1]; the chains of launch k read what it wrote.  Never read and written by one launch.
-//   pwm1[n][4 W]  PWM_j for odd j (even j: the caller's array): launch k reads PWM_(k-2), writes PWM_(k-1) to the other one.
-//   bad[2][n]     bad[k & 1] = "launch k met a weight the scan cannot take" (read by its chains); launch k clears the other.
-struct FusedState {
-  uint32_t* run;       // [2][n]
-  float* pwm0;         // the caller's PWMs (PWM_j, j even)
-  float* pwm1;         // scratch (j odd)
-  uint32_t* bad;       // [2][n]
-  const float* cellsum;  // [n][4 W]: what the chains of the previous launch left
-  int32_t* state;      // the caller's {iterations, running} pairs
-  float* change;       // the caller's `change`
-  uint32_t n;          // PWMs of this batch
-  uint32_t run_stride, bad_stride;  // words between the two copies of run[] / bad[]
-};
-
-// Common head of every workgroup of em_span_fused_kernel: F_(k-1) for PWM pw, or PWM_0 at k = 1.  Leaves the PWM the
-// weights are to be computed from in s_pwm and returns whether the PWM is still running.  `writer`: this workgroup
-// records the step (exactly one workgroup per PWM and launch).
-template <int W>
-__device__ __forceinline__ bool fused_head(const FusedState& fs, uint32_t pw, uint32_t k, float threshold, int max_it, bool writer,
-                                           float* s_pwm, float* s_old, uint32_t t) {
-  constexpr uint32_t CELLS = 4u * W;
-  const uint32_t was_running = fs.run[(size_t)(k & 1u) * fs.run_stride + pw];
-  const float* prev = (k >= 2u && (k & 1u)) ? fs.pwm1 : fs.pwm0;  // PWM_(k-2) (k = 1: PWM_0)
-  float old = 0.0f, sum = 0.0f;
-  if (t < CELLS) {
-    old = prev[(size_t)pw * CELLS + t];
-    if (k >= 2u) sum = fs.cellsum[(size_t)pw * CELLS + t];
-  }
-  if (!was_running) {  // (workgroup-uniform)
-    if (writer && t == 0) {
-      fs.run[(size_t)((k - 1u) & 1u) * fs.run_stride + pw] = 0u;
-      fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
-    }
-    return false;
-  }
-  if (k < 2u) {
-    if (t < CELLS) s_pwm[t] = old;
-    if (writer && t == 0) fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
-    __syncthreads();
-    return true;
-  }
-  if (t < CELLS) {
-    s_pwm[t] = sum;
-    s_old[t] = old;
-  }
-  __syncthreads();
-  const float change = finalize_rows<W>(s_pwm, s_old, t);
-  const int it = (int)k - 1;
-  const bool running = !(change <= threshold || it >= max_it);
-  if (writer) {
-    float* next = (k & 1u) ? fs.pwm0 : fs.pwm1;  // PWM_(k-1)
-    if (t < CELLS) next[(size_t)pw * CELLS + t] = s_pwm[t];
-    if (t == 0) {
-      fs.state[2 * pw] = it;
-      fs.state[2 * pw + 1] = running ? 1 : 0;
-      fs.change[pw] = change;
-      fs.run[(size_t)((k - 1u) & 1u) * fs.run_stride + pw] = running ? 1u : 0u;
-      fs.bad[(size_t)((k + 1u) & 1u) * fs.bad_stride + pw] = 0u;
-    }
-  }
-  return running;
 }
 
 // The weights of a span, as em_weights_kernel computes them, and on the way the span's block sums.  A workgroup per span:
@@ -759,62 +543,6 @@ __global__ __launch_bounds__(64) void em_block_predict_kernel(const uint32_t* __
     out[i] = r;
     before = after;
   }
-}
-
-// A span in LDS, read by every cell that has a block in it: 256 rows of 64 floats; the 16-byte slot k of row R lies at
-// slot k ^ g(R), g(R) = (R ^ R >> 3 ^ R >> 4) & 15.  With that, each of the reads below -- a lane fetching four
-// consecutive terms of ITS row of 64 terms, for every way a cell's terms lie in the span -- puts the sixteen lanes that
-// ds_read_b128 serves together on sixteen different slots (checked for all positions by enumeration; the four cells of
-// position 0, every fourth float, read single dwords and pay 4-way conflicts).
-struct SpanLds {
-  static __device__ __forceinline__ uint32_t g(uint32_t R) { return (R ^ (R >> 3) ^ (R >> 4)) & 15u; }
-  static __device__ __forceinline__ uint32_t slot_of(uint32_t R, uint32_t k) { return R * 16u + (k ^ g(R)); }
-};
-
-// The terms of lane l's row (terms 64 l .. 64 l + 63 of the block) of task (p, j) of a span, from LDS.
-//   p >= 6: block = quarter j of the span (p = 6: the cell (6, j)): x_local = 4096 j + 64 l + i
-//   p = 3, 4, 5: digit p = j lies above the low six bits: whole rows, row index = l with j inserted at bit 2 p - 6
-//   p = 1, 2: rows 4 l .. 4 l + 3, a quarter of each;  p = 0: every fourth float of those rows
-template <int W>
-__device__ __forceinline__ void span_row(const float* span, uint32_t p, uint32_t j, uint32_t l, seqsum::Row& row) {
-  typedef seqsum::f4 f4;
-  const f4* s4 = reinterpret_cast<const f4*>(span);
-  if (p >= 3u) {
-    uint32_t R;
-    if (p >= 6u) {
-      R = 64u * j + l;
-    } else {
-      const uint32_t sh = 2u * p - 6u;
-      R = ((l >> sh) << (sh + 2u)) | (j << sh) | (l & ((1u << sh) - 1u));
-    }
-    const uint32_t base = R * 16u + SpanLds::g(R);
-#pragma unroll
-    for (uint32_t k = 0; k < 16u; ++k) row.q[k] = s4[base ^ k];
-  } else if (p != 0u) {
-    // g(4 l + c) = g(4 l) ^ c: slot (s ^ g) of row 4 l + c lies at (64 l + g(4 l)) ^ (16 c + (s ^ c))
-    const uint32_t base = 64u * l + SpanLds::g(4u * l);
-    if (p == 2u) {
-#pragma unroll
-      for (uint32_t k = 0; k < 16u; ++k) row.q[k] = s4[base ^ (16u * (k >> 2) + (((k & 3u) + 4u * j) ^ (k >> 2)))];
-    } else {
-#pragma unroll
-      for (uint32_t k = 0; k < 16u; ++k) row.q[k] = s4[base ^ (16u * (k >> 2) + ((4u * (k & 3u) + j) ^ (k >> 2)))];
-    }
-  } else {
-    const uint32_t base = 4u * (64u * l + SpanLds::g(4u * l)) + j;  // (in floats; j < 4 stays below the slot bits)
-#pragma unroll
-    for (uint32_t k = 0; k < 16u; ++k) {
-      // terms 4 k .. 4 k + 3: row 4 l + (k >> 2), slots 4 (k & 3) .. + 3, component j
-      const uint32_t c = k >> 2;
-      row.q[k].x = span[base ^ (4u * (16u * c + ((4u * (k & 3u) + 0u) ^ c)))];
-      row.q[k].y = span[base ^ (4u * (16u * c + ((4u * (k & 3u) + 1u) ^ c)))];
-      row.q[k].z = span[base ^ (4u * (16u * c + ((4u * (k & 3u) + 2u) ^ c)))];
-      row.q[k].w = span[base ^ (4u * (16u * c + ((4u * (k & 3u) + 3u) ^ c)))];
-    }
-  }
-  asm volatile("" : "+v"(row.q[0]), "+v"(row.q[1]), "+v"(row.q[2]), "+v"(row.q[3]), "+v"(row.q[4]), "+v"(row.q[5]), "+v"(row.q[6]),
-               "+v"(row.q[7]), "+v"(row.q[8]), "+v"(row.q[9]), "+v"(row.q[10]), "+v"(row.q[11]), "+v"(row.q[12]), "+v"(row.q[13]),
-               "+v"(row.q[14]), "+v"(row.q[15]));
 }
 
 // One workgroup per span: the span's 64 KiB are read ONCE (not once per position) into LDS, and the eight waves share
@@ -1000,326 +728,7 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
   PENGK_WG_TRACE_END(0, lin);
 }
 
-// ---- weights, block sums, estimates and block evaluation as ONE kernel (em_serial_scan = 3; W = 10, 12) -----------------
-// An iteration of the blocks-ahead scheme above was three dependent launches -- weights (table + block sums), block
-// evaluation (the table read back, span by span), chains -- with the finalize step at the end of the last one, behind an
-// arrival counter.  Here it is two:
-//   em_span_fused_kernel   a workgroup per span: the PREVIOUS iteration's finalize step at its head (every workgroup of a
-//                          PWM repeats the 4 W divisions from the cell sums the chains left -- no arrival protocol, no
-//                          launch), the span's weights computed into LDS (and stored once, for the chains' fetches),
-//                          the span's block sums published, the estimates of the sums in front of its blocks from a
-//                          LOOK-BACK over the earlier spans of the PWM, the blocks evaluated from LDS;
-//   em_chain_store_kernel  one wave per cell walks the records (seqsum::walk_chain) and stores the cell's sum.
-// The table is written once and read only where a chain takes a block the long way (W = 12: 64 MiB per PWM and iteration
-// instead of 64 written + 64 read).
-//
-// The look-back.  Span sp publishes A[sp][cell] = what its weights add to each of the 4 W cells, as 64-bit words {epoch of
-// this launch, float}: one relaxed device-scope store per cell, data and "ready" in one word, no fence.  A workgroup adds
-// up the words of the earlier spans of its chunk of 64 -- eight per wave, all requested at once -- and the chunk totals
-// T[c] of the earlier chunks, which the last span of every chunk publishes the same way.  It only ever waits for
-// workgroups with a SMALLER linear index, and the wait is BOUNDED: when the deadline (LOOKBACK_TICKS of the 100 MHz
-// clock) passes, the workgroup marks its blocks "no binade" and goes on -- the chain then folds them term by term, which
-// costs time and never the result (seqsum.h: exactness does not rest on the estimates).  So neither an unexpected
-// dispatch order nor a lost workgroup can hang the launch.  Test hook em_test_lookback = n: every n-th workgroup acts as
-// if its deadline had passed.
-// per-call counters of what the chains met (pengk_get_info "em_*"): fetched, mispredicted, restaged, restaged_waits
-// (seqsum::WalkCounts); behind them in the same allocation: the background table's {min, max}
-constexpr int EM_COUNTERS = 4;
-struct FusedGeo {
-  static constexpr uint32_t THREADS = 512, WAVES = 8, CHUNK = 64;
-  static constexpr unsigned long long LOOKBACK_TICKS = 50000ull;  // 500 us
-};
-template <int W>
-struct LookGeo {
-  using G = BlockGeo<W>;
-  static constexpr uint32_t CHUNKS = (G::SPANS + FusedGeo::CHUNK - 1u) / FusedGeo::CHUNK;
-  static constexpr bool SUPPORTED = CHUNKS <= 64u;  // two levels: the earlier spans of a chunk, the earlier chunks (W = 14 would take a third)
-  static constexpr size_t WORDS_PER_PWM = (size_t)(G::SPANS + CHUNKS) * G::CELLS;  // A[span][cell] | T[chunk][cell]
-};
-__device__ __forceinline__ unsigned long long look_word(uint32_t epoch, float v) {
-  uint32_t b = __float_as_uint(v);
-  if (b > 0x7F800000u) b = 0x7F800000u;  // (a NaN or a negative sum -- degenerate weights -- travels as +inf: no binade)
-  return ((unsigned long long)epoch << 32) | b;
-}
-__device__ __forceinline__ unsigned long long look_load(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int W>
-__global__ __launch_bounds__(FusedGeo::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void em_span_fused_kernel(FusedState fs, uint32_t k, float threshold, int max_it,
-                                                                          const uint32_t* __restrict__ counts,
-                                                                          const float* __restrict__ bg, float saturation,
-                                                                          float* __restrict__ wbuf, seqsum::BlockRecord* __restrict__ rec,
-                                                                          unsigned long long* __restrict__ look, uint32_t epoch,
-                                                                          const uint32_t* __restrict__ bg_range, uint32_t skew,
-                                                                          uint32_t test_lookback) {
-  using G = BlockGeo<W>;
-  using LG = LookGeo<W>;
-  constexpr uint32_t CELLS = G::CELLS, WAVES = FusedGeo::WAVES;
-  PENGK_WG_TRACE_BEGIN(2);
-  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
-  __shared__ __attribute__((aligned(16))) float span[16384];
-  __shared__ __attribute__((aligned(16))) float s_pwm[CELLS], s_old[CELLS];
-  __shared__ float s_part[WAVES][28];
-  __shared__ float s_cell[CELLS];        // what this span adds to each cell
-  __shared__ float s_look[2][WAVES][CELLS];  // the waves' shares of the look-back: [0] earlier spans of the chunk, [1] earlier chunks
-  __shared__ uint32_t s_ok[WAVES];
-  __shared__ uint32_t s_lean;
-  const uint32_t t = threadIdx.x, lane = t & 63u;
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
-  uint32_t* bad_now = fs.bad + (size_t)(k & 1u) * fs.bad_stride;
-  const uint32_t bg_lo = bg_range[0], bg_hi = bg_range[1];
-
-  const uint32_t sl = lin, slot = sl >> 3;
-  const uint32_t pw = (sl & 7u) + 8u * (slot / G::SPANS), sp = slot % G::SPANS;
-  if (pw >= fs.n) return;
-  const uint32_t* cnt = counts + (size_t)sp * 16384u;
-  const float* bgs = bg + (size_t)sp * 16384u;
-  if (!fused_head<W>(fs, pw, k, threshold, max_it, sp == 0u, s_pwm, s_old, t)) return;
-  if (t == 0) s_lean = lean_ranges_ok<W>(s_pwm, bg_lo, bg_hi, saturation) ? 1u : 0u;  // (workgroup-uniform: one PWM, one table)
-  __syncthreads();
-  const bool lean = s_lean != 0u;
-  PENGK_WG_TRACE_END(4, lin);  // (the head is done)
-
-  // ---- the span's weights: thread = digits 0..3 of x (t & 255) and the upper half of digit 6 (t >> 8); 32 x per thread
-  // over digits 4, 5 and the lower half of digit 6.  The product over the PWM's columns in the reference's order.
-  unsigned long long* my_look = look + (size_t)pw * LG::WORDS_PER_PWM;
-  // (look-back, below: wave w adds the earlier spans j = w (mod 8) of its chunk and the earlier chunks c = w (mod 8); the
-  // words are ASKED FOR here, behind the weights and in front of the reductions and the barrier -- the earlier spans
-  // started earlier, most of their words are there by now, and the round trip is hidden)
-  const uint32_t chunk = sp / FusedGeo::CHUNK, c0 = chunk * FusedGeo::CHUNK, n0 = sp - c0;
-  constexpr uint32_t PER = FusedGeo::CHUNK / WAVES;              // spans per wave
-  constexpr uint32_t PERC = (LG::CHUNKS + WAVES - 1u) / WAVES;   // chunk totals per wave
-  const unsigned long long* src[PER + PERC];
-  unsigned long long v[PER + PERC];
-  bool need[PER + PERC];
-  {
-    float* out_t = wbuf + (size_t)pw * G::NP + (size_t)sp * 16384u + (t & 255u);
-    const uint32_t* cnt_t = cnt + (t & 255u);
-    const float* bg_t = bgs + (t & 255u);
-    const uint32_t tl = t & 255u, h = t >> 8, w3 = (t >> 6) & 3u;
-    float p3 = 1.0f;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) p3 = p3 * s_pwm[p * 4 + ((tl >> (2 * p)) & 3u)];
-    float hi[W - 7];  // the span's own digits 7 .. W-1 (wave-uniform)
-#pragma unroll
-    for (int p = 7; p < W; ++p) hi[p - 7] = s_pwm[p * 4 + ((sp >> (2 * (p - 7))) & 3u)];
-    float f4_[4], f5_[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      f4_[a] = s_pwm[16 + a];
-      f5_[a] = s_pwm[20 + a];
-    }
-    float c4[4] = {0, 0, 0, 0}, c5[4] = {0, 0, 0, 0}, c6[2] = {0, 0};
-    uint32_t worst = 0u;  // the largest bit pattern among the weights: above +inf's = negative or NaN
-    // LDS: float xl of the span lies at 4 (R 16 + (k ^ g(R))) + (xl & 3), R = xl >> 6, k = (xl >> 2) & 15 (SpanLds).  With
-    // xl = tl + 256 (d4 + 4 d5 + 16 d6): R = w3 + 4 d4 + 16 d5 + 64 d6 and g(R) = w3 ^ C(d4, d5) ^ G6(d6), so the byte
-    // address is (a6 ^ 16 C(d4, d5)) + 256 (4 d4 + 16 d5) with a6 per thread and d6: one xor per x.
-    const uint32_t kslot = (tl >> 2) & 15u, comp = tl & 3u;
-    char* span_b = reinterpret_cast<char*>(span);
-    auto body = [&](auto lean_tag) {
-      constexpr bool LEAN = decltype(lean_tag)::value;
-#pragma unroll 1
-      for (uint32_t i6 = 0; i6 < 2u; ++i6) {  // (not unrolled: 16 x in flight per turn keep the kernel at 128 registers, two workgroups per CU)
-        const uint32_t d6 = 2u * h + i6;
-        const float f6 = s_pwm[24 + d6];
-        const uint32_t g6 = (((d6 & 1u) << 3) ^ ((d6 & 3u) << 2)) & 15u;
-        const uint32_t a6 = 256u * (w3 + 64u * d6) + 4u * comp + 16u * ((kslot ^ w3 ^ g6) & 15u);
-        float* out6 = out_t + 4096u * d6;
-        const uint32_t* cnt6 = cnt_t + 4096u * d6;
-        const float* bg6 = bg_t + 4096u * d6;
-        float s6 = 0.0f;
-#pragma unroll
-        for (uint32_t d5 = 0; d5 < 4u; ++d5) {
-          float s5 = 0.0f;
-#pragma unroll
-          for (uint32_t d4 = 0; d4 < 4u; ++d4) {
-            constexpr uint32_t dummy = 0u;
-            (void)dummy;
-            const uint32_t m2 = d4 + 4u * d5;
-            const uint32_t cc = ((d4 << 2) ^ (d4 >> 1) ^ (d5 << 1) ^ d5) & 15u;
-            float pr = ((p3 * f4_[d4]) * f5_[d5]) * f6;
-#pragma unroll
-            for (int p = 7; p < W; ++p) pr = pr * hi[p - 7];
-            const float odds = em_div<LEAN>(pr, bg6[256u * m2]);
-            const float v = em_div<LEAN>((float)cnt6[256u * m2] * saturation, 1 + em_div<LEAN>(saturation, odds));  // :124-125
-            out6[256u * m2] = v;
-            *reinterpret_cast<float*>(span_b + ((a6 ^ (16u * cc)) + 256u * (4u * d4 + 16u * d5))) = v;
-            worst = max(worst, __float_as_uint(v));
-            c4[d4] += v;
-            s5 += v;
-          }
-          c5[d5] += s5;
-          s6 += s5;
-        }
-        c6[0] += i6 ? 0.0f : s6;
-        c6[1] += i6 ? s6 : 0.0f;
-      }
-    };
-    if (lean) body(std::true_type{});
-    else body(std::false_type{});
-    if (worst > 0x7F7FFFFFu) bad_now[pw] = 1u;  // (this PWM's cells are summed by the chain kernel's plain loop)
-#pragma unroll
-    for (uint32_t i = 0; i < PER; ++i) {
-      const uint32_t j = wave + WAVES * i;
-      need[i] = j < n0 && lane < CELLS;
-      src[i] = my_look + (size_t)(c0 + (j < n0 ? j : 0u)) * CELLS + (lane < CELLS ? lane : 0u);
-    }
-#pragma unroll
-    for (uint32_t i = 0; i < PERC; ++i) {
-      const uint32_t c = wave + WAVES * i;
-      need[PER + i] = c < chunk && lane < CELLS;
-      src[PER + i] = my_look + (size_t)(G::SPANS + (c < chunk ? c : 0u)) * CELLS + (lane < CELLS ? lane : 0u);
-    }
-#pragma unroll
-    for (uint32_t i = 0; i < PER + PERC; ++i) v[i] = need[i] ? look_load(src[i]) : 0ull;
-    // per wave: whole-wave sums by digit 4, 5, 6; the total by digit 0, 1, 2 (lane bits 0-1, 2-3, 4-5); the total (digit 3)
-    const float tot = c6[0] + c6[1];
-    auto all = [](float v) {
-#pragma unroll
-      for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-      return v;
-    };
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const float s4 = all(c4[a]), s5 = all(c5[a]);
-      if (lane == 0) {
-        s_part[wave][12 + a] = s4;
-        s_part[wave][16 + a] = s5;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float s6 = all(c6[i]);
-      if (lane == 0) s_part[wave][20 + i] = s6;
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {  // digit d = lane bits 2 d, 2 d + 1: add over the other four bits
-      float v = tot;
-#pragma unroll
-      for (int m = 1; m < 64; m <<= 1)
-        if (m != (1 << (2 * d)) && m != (2 << (2 * d))) v += __shfl_xor(v, m, 64);
-      if ((lane & ~(3u << (2 * d))) == 0u) s_part[wave][4 * d + (lane >> (2 * d))] = v;
-    }
-    {
-      const float v = all(tot);
-      if (lane == 0) s_part[wave][24] = v;
-    }
-  }
-  PENGK_WG_TRACE_END(3, lin);  // (this thread's weights are done)
-  __syncthreads();  // the span and the waves' partial sums are in LDS
-
-  // ---- what the span adds to every cell; published for the later spans of the PWM
-  if (t < CELLS) {
-    const uint32_t p = t >> 2, a = t & 3u;
-    auto over_waves = [&](uint32_t at) {
-      float v = 0.0f;
-#pragma unroll
-      for (uint32_t w = 0; w < WAVES; ++w) v += s_part[w][at];
-      return v;
-    };
-    float v;
-    if (p <= 2u) v = over_waves(4u * p + a);
-    else if (p == 3u) v = s_part[a][24] + s_part[a + 4u][24];  // digit 3 = wave & 3
-    else if (p <= 5u) v = over_waves(4u * (p - 1u) + a);        // digits 4, 5 at 12, 16
-    else {
-      // digit 6 = 2 (wave >> 2) + i; for p >= 7 the span lies in ONE cell of the position, whole
-      const uint32_t w0 = 4u * (a >> 1), at = 20u + (a & 1u);
-      const float q = (s_part[w0][at] + s_part[w0 + 1u][at]) + (s_part[w0 + 2u][at] + s_part[w0 + 3u][at]);
-      if (p == 6u) v = q;
-      else v = a == G::high_digit(p, sp) ? over_waves(24u) : 0.0f;
-    }
-    s_cell[t] = v;
-    __hip_atomic_store(my_look + (size_t)sp * CELLS + t, look_word(epoch, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-
-  // ---- look-back: what is not there yet is asked for again until it is, or until the deadline
-  {
-    bool ok = true;
-    const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + FusedGeo::LOOKBACK_TICKS;
-    float acc = 0.0f, acc_spans = 0.0f;
-#pragma unroll
-    for (uint32_t i = 0; i < PER + PERC; ++i) {
-      if (i == PER) {
-        acc_spans = acc;
-        acc = 0.0f;
-      }
-      // (the wave polls together: it leaves the loop when no lane waits any more, or at the deadline)
-      while (__builtin_amdgcn_ballot_w64(need[i] && (uint32_t)(v[i] >> 32) != epoch) != 0ull) {
-        if (__builtin_amdgcn_s_memrealtime() > deadline) {
-          ok = false;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-        if (need[i] && (uint32_t)(v[i] >> 32) != epoch) v[i] = look_load(src[i]);
-      }
-      if (need[i] && (uint32_t)(v[i] >> 32) == epoch) acc += __uint_as_float((uint32_t)v[i]);
-    }
-    ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-    if (lane < CELLS) {
-      s_look[0][wave][lane] = acc_spans;
-      s_look[1][wave][lane] = acc;
-    }
-    if (lane == 0) s_ok[wave] = ok ? 1u : 0u;
-  }
-  __syncthreads();
-  bool est_ok = true;
-#pragma unroll
-  for (uint32_t w = 0; w < WAVES; ++w) est_ok &= s_ok[w] != 0u;
-  // the last span of a chunk publishes the chunk's total (earlier spans of the chunk + its own)
-  if (est_ok && (sp % FusedGeo::CHUNK) == FusedGeo::CHUNK - 1u && t < CELLS) {
-    float tot = s_cell[t];
-#pragma unroll
-    for (uint32_t w = 0; w < WAVES; ++w) tot += s_look[0][w][t];
-    __hip_atomic_store(my_look + (size_t)(G::SPANS + sp / FusedGeo::CHUNK) * CELLS + t, look_word(epoch, tot), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // (test hook: every n-th workgroup acts as if its deadline had passed -- after it has done its duty to the later chunks)
-  if (test_lookback != 0u && (lin * 2654435761u >> 20) % test_lookback == 0u) est_ok = false;
-  PENGK_WG_TRACE_END(2, lin);  // (the span is in LDS, the estimates are known)
-
-  // ---- the blocks of the span: task (p, j) -> its cell and block, as in em_span_eval_kernel
-  seqsum::BlockRecord* cells = rec + (size_t)pw * CELLS * G::NBLK;
-  auto cell_of = [&](uint32_t task) { return (task >> 2) <= 6u ? task : 4u * (task >> 2) + G::high_digit(task >> 2, sp); };
-  auto block_of = [&](uint32_t task) { return (task >> 2) <= 6u ? sp : G::high_block(task >> 2, sp, task & 3u); };
-#pragma unroll 1
-  for (uint32_t task = wave; task < CELLS; task += WAVES) {
-    const uint32_t p = task >> 2, j = task & 3u;
-    const uint32_t cell = cell_of(task), b = block_of(task);
-    seqsum::BlockRecord* r = cells + (size_t)cell * G::NBLK + b;
-    uint32_t e = seqsum::NO_BINADE;
-    float before = 0.0f;
-    if (est_ok) {
-#pragma unroll
-      for (uint32_t w = 0; w < WAVES; ++w) before += s_look[0][w][cell] + s_look[1][w][cell];
-      float own = s_cell[cell];
-      if (p >= 7u) {  // quarter j of the span: the quarters in front of it belong to the same cell
-        for (uint32_t q = 0; q < j; ++q) before += s_cell[24u + q];
-        own = s_cell[24u + j];
-      }
-      e = block_binade((double)before, (double)before + (double)own, skew, cell * G::NBLK + b);
-    }
-    if (e == seqsum::NO_BINADE) {  // (block 0, where the sum climbs from zero, and the blocks where it passes a power of two: folded by the chain)
-      if (lane == 0) r->e = seqsum::NO_BINADE;
-      continue;
-    }
-    seqsum::Row mine;
-    span_row<W>(span, p, j, lane, mine);
-    float d0, d1;
-    const bool ok = seqsum::block_increments(mine, lane, seqsum::bases_of_binade(e), d0, d1);
-    if (lane == 0) {
-      seqsum::BlockRecord out;
-      out.e = ok ? e : seqsum::NO_BINADE;
-      out.d0 = d0;
-      out.d1 = d1;
-      out.pad = 0u;
-      *r = out;
-    }
-  }
-  PENGK_WG_TRACE_END(0, lin);
-}
-
-// The chains of a launch of em_span_fused_kernel: one wave per cell; the cell's sum is stored for the next launch's head
+// The chains of an iteration: one wave per cell; the cell's sum is stored for the next iteration's head
 // (or em_serial_finish_kernel) -- a plain store, the kernel boundary orders it.
 template <int W>
 __global__ __launch_bounds__(64) void em_chain_store_kernel(const uint32_t* __restrict__ run, const uint32_t* __restrict__ bad,
@@ -1632,9 +1041,10 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
             const uint64_t wgs = (uint64_t)groups * B::SPANS;
             const unsigned gx = 1024u;
             const uint32_t epoch = ++ctx->em_epoch;
-            hipLaunchKernelGGL((em_span_fused_kernel<W>), dim3(gx, (unsigned)((wgs + gx - 1) / gx)), dim3(FusedGeo::THREADS), 0, st, fs, k,
-                               threshold, max_it, d_counts, d_bg, saturation, tables, rec, look, epoch, (const uint32_t*)bg_range,
-                               (uint32_t)ctx->em_test_skew, (uint32_t)ctx->em_test_lookback);
+            const int rc_fused = launch_span_fused(W, gx, (unsigned)((wgs + gx - 1) / gx), st, fs, k, threshold, max_it, d_counts, d_bg, saturation,
+                                                   tables, rec, look, epoch, (const uint32_t*)bg_range, (uint32_t)ctx->em_test_skew,
+                                                   (uint32_t)ctx->em_test_lookback);  // (em_fused.hip)
+            if (rc_fused) return rc_fused;
           }
           hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
                              (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters);
