@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--fast", type=int, default=2)
     ap.add_argument("--lean", type=int, default=1, help="option em_lean_div")
     ap.add_argument("--head", type=int, default=-1, help="option em_head_blocks")
+    ap.add_argument("--budget", type=int, default=-1, help="option em_table_budget_mb")
     ap.add_argument("--scan", type=int, default=2, help="pengk_test_em_generation (2 = the library's scheme, 3 = two launches per iteration, 1 = scan, 0 = fold)")
     a = ap.parse_args()
     W, NP = a.W, 4 ** a.W
@@ -53,6 +54,8 @@ def main():
     ctx.test_em_generation(a.scan)
     if a.head >= 0:
         ctx.set_option("em_head_blocks", a.head)
+    if a.budget >= 0:
+        ctx.set_option("em_table_budget_mb", a.budget)
     if a.streams:
         ctx.set_option("em_overlap", a.streams)
     t0, t1 = ctx.timer(), ctx.timer()
@@ -65,7 +68,7 @@ def main():
         ms.append(ctx.elapsed_ms(t0, t1))
     ms = sorted(ms[2:])
     met = {k: ctx.info("em_" + k) for k in ("fetched_blocks", "mispredicted_blocks", "restaged_blocks", "restaged_waits")} if a.fast == 2 else {}
-    print("scan=%d streams=%d head=%d " % (a.scan, a.streams, a.head), end="")
+    print("scan=%d streams=%d head=%d budget=%d " % (a.scan, a.streams, a.head, a.budget), end="")
     print("W=%d pwms=%d iters=%d: best %.4f ms  median %.4f ms  (%.2f us per iteration)  %s" % (
         W, a.pwms, a.iters, ms[0], ms[len(ms) // 2], ms[len(ms) // 2] * 1e3 / a.iters, met), flush=True)
     import hashlib
