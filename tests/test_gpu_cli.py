@@ -164,6 +164,47 @@ def test_cli_random_inputs_against_reference_binary(tmp_path, seed, flags):
     compare_outputs(*outs["here"], outs["ref"][0], outs["ref"][1], outs["ref"][2], "--no-em" not in flags)
 
 
+@pytest.mark.parametrize("flags", [["-w", "8"], ["-w", "10", "--strand", "PLUS"]])
+def test_cli_genome_scale_records_against_reference_binary(tmp_path, flags):
+    """Records far longer than any item or reader chunk: one of 3 Mbp written as ONE line, one of 1.2 Mbp in 60-column
+    lines with a poly-A run of 40 kbp and a stretch of N inside, one shorter than the pattern, a few hundred ordinary ones
+    with a planted motif -- the sharded reader, the item splitter (a record becomes thousands of items whose non-overlap
+    state crosses item borders) and the deferred fix-up against the compiled reference, byte for byte."""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/peng_motif_ref not present (the reference is only built in the build container)")
+    rng = np.random.default_rng(77)
+    acgt = np.array(list("ACGT"))
+    motif = "GCTGAGTCAT"
+
+    def plant(a, every):
+        for at in range(1000, len(a) - 20, every):
+            a[at:at + len(motif)] = list(motif)
+        return a
+    big = plant(acgt[rng.integers(0, 4, 3_000_000)], 9973)
+    mid = plant(acgt[rng.integers(0, 4, 1_200_000)], 7919)
+    mid[300_000:340_000] = "A"
+    mid[500_000:500_700] = "N"
+    with open(tmp_path / "g.fa", "w") as f:
+        f.write(">chrBig\n" + "".join(big) + "\n")
+        f.write(">chrMid\n")
+        m = "".join(mid)
+        f.write("\n".join(m[i:i + 60] for i in range(0, len(m), 60)) + "\n")
+        f.write(">tiny\nACGTA\n")
+        for i in range(300):
+            s = acgt[rng.integers(0, 4, int(rng.integers(80, 400)))]
+            if i % 3 == 0:
+                s[20:20 + len(motif)] = list(motif)
+            f.write(">r%d\n%s\n" % (i, "".join(s)))
+    outs = {}
+    for tag, exe in (("ref", REF_CLI), ("here", CLI)):
+        meme, js = str(tmp_path / (tag + ".meme")), str(tmp_path / (tag + ".json"))
+        r = subprocess.run([exe, str(tmp_path / "g.fa")] + flags + ["-o", meme, "-j", js], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert r.returncode == 0, (tag, r.stderr.decode()[-2000:])
+        outs[tag] = (meme, js, r.stdout.decode())
+    assert "MOTIF" in open(outs["ref"][0]).read()
+    compare_outputs(*outs["here"], outs["ref"][0], outs["ref"][1], outs["ref"][2], True)
+
+
 @pytest.mark.parametrize("with_bg", [False, True])
 def test_cli_stderr_warnings_match_the_reference(tmp_path, with_bg):
     """stderr: the reference warns about records without sequence as it meets them and about undefined bases only in the
