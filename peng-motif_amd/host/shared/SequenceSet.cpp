@@ -7,12 +7,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <limits>
 #include <thread>
+#include <vector>
 
 void* sequence_set_huge_alloc(std::size_t bytes) {
   if (bytes == 0) bytes = 1;
@@ -372,15 +374,49 @@ void SequenceSet::readFASTA(const SequenceChunkSink& sink) {
 
   // ---- this rank's part of the file: everything a single process does with the whole file ---------------------------
   auto local_pass = [&]() -> int {
-    const int fd = open(path_.c_str(), O_RDONLY);
+    int fd = open(path_.c_str(), O_RDONLY);
     struct FdGuard {
-      int fd;
+      int& fd;
       ~FdGuard() {
         if (fd >= 0) close(fd);
       }
     } fd_guard{fd};
     struct stat sb;
-    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return FASTA_OPEN;
+    if (fd < 0 || fstat(fd, &sb) != 0) return FASTA_OPEN;
+    if (!S_ISREG(sb.st_mode)) {
+      // The reference reads through std::ifstream + getline (src/shared/SequenceSet.cpp:285-300): a directory opens and
+      // yields no line -- an empty set, exit code 0 --, a pipe or a device is read to its end.  Here: a directory is an
+      // empty file; anything else that is not a regular file is spooled into an anonymous memory file first (one process
+      // only: several ranks cannot share a pipe).
+      if (S_ISDIR(sb.st_mode)) {
+        sb.st_size = 0;
+      } else {
+        if (sc.world > 1) return FASTA_OPEN;
+        const int spool = memfd_create("pengk_fasta", MFD_CLOEXEC);
+        if (spool < 0) return FASTA_OPEN;
+        std::vector<char> buf(1u << 20);
+        bool ok = true;
+        for (;;) {
+          const ssize_t n = read(fd, buf.data(), buf.size());
+          if (n < 0 && errno == EINTR) continue;
+          if (n < 0) ok = false;
+          if (n <= 0) break;
+          for (ssize_t done = 0; done < n;) {
+            const ssize_t w = write(spool, buf.data() + done, (size_t)(n - done));
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) {
+              ok = false;
+              break;
+            }
+            done += w;
+          }
+          if (!ok) break;
+        }
+        close(fd);
+        fd = spool;
+        if (!ok || fstat(fd, &sb) != 0) return FASTA_OPEN;
+      }
+    }
     size_t file_size = (size_t)sb.st_size;
     // the reference's getline(...).good() loop never yields a final line without '\n'
     {

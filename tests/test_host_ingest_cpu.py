@@ -85,6 +85,38 @@ def test_reader_error_exits(tmp_path):
         assert r.returncode == 1
 
 
+def test_reader_on_paths_that_are_not_regular_files(tmp_path):
+    """The reference reads through std::ifstream + getline (src/shared/SequenceSet.cpp:285-300): a DIRECTORY opens and
+    yields no line -- an empty set, not an error (checked against the compiled reference: exit code 0, the empty file's
+    stdout) --, a pipe is read to its end.  The mirror's pread-based reader treats a directory as an empty file and spools
+    a pipe into memory: same dump as the same bytes in a file; a missing path is still the reference's error."""
+    subprocess.run(["make", "-s", "-C", os.path.dirname(DUMP), "host_ingest_dump"], check=True)
+    text = ">a\nACGTACGTACNNACGT\n>b\nGGGTTTAAcc\n>c\n" + "ACGTTGCA" * 5000 + "\n"
+    f = tmp_path / "x.fa"
+    f.write_text(text)
+    want = subprocess.run([DUMP, str(f)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert want.returncode == 0
+    fifo = tmp_path / "pipe.fa"
+    os.mkfifo(fifo)
+    p = subprocess.Popen([DUMP, str(fifo)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    with open(fifo, "w") as w:
+        w.write(text)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 0 and out == want.stdout
+    with open(f, "rb") as src:
+        r = subprocess.run([DUMP, "/dev/stdin"], stdin=src, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 0 and r.stdout == want.stdout
+    empty = tmp_path / "empty.fa"
+    empty.write_text("")
+    d = tmp_path / "dir.fa"
+    d.mkdir()
+    a = subprocess.run([DUMP, str(empty)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    b = subprocess.run([DUMP, str(d)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert a.returncode == b.returncode == 0 and a.stdout == b.stdout and a.stdout.startswith(b"N 0 ")
+    r = subprocess.run([DUMP, str(tmp_path / "missing.fa")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and b"Cannot open FASTA file" in r.stderr
+
+
 def test_seed_ranking_replays_std_sort():
     """select_base_patterns ranks with ranked_prefix.h (a replay of libstdc++'s introsort that stops below the z
     threshold); the reference ranks with std::sort (src/base_pattern.cpp:458).  The CPU-only harness compares the two on
