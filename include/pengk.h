@@ -270,6 +270,7 @@ int pengk_iupac_aggregate(pengk_ctx* ctx, int W, int both_strands, const uint64_
  * Modes 0 and 1 agree with the reference within BASELINE.json's 1e-5 relative (the reference's own serial float32
  * sums are off by up to 2.6e-4 relative from the exact ones); the float32 product over the PWM columns is built in
  * the reference's order in all modes.
+ * max_iterations <= 0: no iteration (the reference's loop condition, src/peng.cpp:104), the PWMs come back unchanged.
  * h_iters / h_change (optional): iterations run and last `change` per PWM. */
 int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturation, float threshold,
              int max_iterations, const uint32_t* d_counts, const float* d_bg, int* h_iters, float* h_change);

@@ -575,7 +575,8 @@ int pengk_em_device(pengk_ctx* ctx, int W, int64_t n_pwm, float* d_pwms, float s
   if (!ctx || !d_pwms || !d_counts || !d_bg || !d_state || !d_change) return fail(PENGK_ERR_ARG, "pengk_em_device: NULL argument");
   PENGK_ENTER(ctx);
   if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
-  if (n_pwm < 0 || max_it < 0) return fail(PENGK_ERR_ARG, "negative count");
+  if (n_pwm < 0) return fail(PENGK_ERR_ARG, "negative count");
+  if (max_it < 0) max_it = 0;  // (the reference's loop ends at `iteration_counter >= max_iterations`, src/peng.cpp:104: no iteration)
   if (n_pwm == 0) return PENGK_OK;
   return launch_em(ctx, W, n_pwm, d_pwms, saturation, threshold, max_it, d_counts, d_bg, d_state, d_change);
 }
@@ -585,7 +586,8 @@ int pengk_em(pengk_ctx* ctx, int W, int64_t n_pwm, float* h_pwms, float saturati
   if (!ctx || (n_pwm && !h_pwms) || !d_counts || !d_bg) return fail(PENGK_ERR_ARG, "pengk_em: NULL argument");
   PENGK_ENTER(ctx);
   if (!valid_w(W)) return fail(PENGK_ERR_ARG, "pattern length %d unsupported", W);
-  if (n_pwm < 0 || max_it < 0) return fail(PENGK_ERR_ARG, "negative count");
+  if (n_pwm < 0) return fail(PENGK_ERR_ARG, "negative count");
+  if (max_it < 0) max_it = 0;  // (the reference's loop ends at `iteration_counter >= max_iterations`, src/peng.cpp:104: no iteration)
   if (n_pwm == 0) return PENGK_OK;
   const size_t pw = (size_t)n_pwm * W * 4 * sizeof(float);
   const size_t st = (size_t)n_pwm * 2 * sizeof(int32_t);

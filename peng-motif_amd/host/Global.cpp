@@ -5,7 +5,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <iostream>
+#include <string>
+#include <sys/time.h>
 
 char* Global::alphabetType = (char*)"STANDARD";
 char* Global::outputFilename = nullptr;
@@ -67,12 +70,25 @@ void Global::destruct() {
 }
 
 namespace {
+// A line of the reference's logger (src/log.h:42-57, 119-130; only its argument parser uses it): "- HH:MM:SS.mmm LEVEL: "
+// in front, and -- every call site ends its message with std::endl, the logger adds its own -- an empty line behind.
+void log_line(const char* level, const std::string& msg) {
+  char clock[11];
+  time_t t;
+  time(&t);
+  tm r = {};
+  strftime(clock, sizeof clock, "%X", localtime_r(&t, &r));
+  struct timeval tv;
+  gettimeofday(&tv, nullptr);
+  fprintf(stderr, "- %s.%03ld %s: %s\n\n", clock, (long)tv.tv_usec / 1000, level, msg.c_str());
+  fflush(stderr);
+}
 // value of an option that needs one; exits with 4 like the reference when it is missing
 const char* need(int& i, int nargs, char* args[], void (*help)()) {
   const char* opt = args[i];
   if (++i >= nargs) {
     help();
-    std::cerr << "ERROR: No expression following " << opt << std::endl;
+    log_line("ERROR", std::string("No expression following ") + opt);
     exit(4);
   }
   return args[i];
@@ -99,7 +115,7 @@ void Global::readArguments(int nargs, char* args[]) {
     if (!strcmp(a, "-w")) {
       patternLength = std::stoi(need(i, nargs, args, printHelp));
       if (patternLength % 2 == 1) {
-        std::cerr << "ERROR: Due to optimizations the pattern length has to be a multiple of 2" << std::endl;
+        log_line("ERROR", "Due to optimizations the pattern length has to be a multiple of 2");
         exit(4);
       }
     } else if (!strcmp(a, "--background-sequences")) {
@@ -110,7 +126,8 @@ void Global::readArguments(int nargs, char* args[]) {
       else if (!strcmp(v, "ENRICHMENT")) optScoreType = OPTIMIZATION_SCORE::kExpCounts;
       else if (!strcmp(v, "MUTUAL_INFO")) optScoreType = OPTIMIZATION_SCORE::MutualInformation;
       else {
-        std::cerr << "ERROR: Unknown optimization score (not in {ENRICHMENT, LOGPVAL, MUTUAL_INFO})" << std::endl;
+        printHelp();
+        log_line("ERROR", "Unknown expression following --optimization_score");
         exit(4);
       }
     } else if (!strcmp(a, "--enrich_pseudocount_factor")) {
@@ -152,13 +169,14 @@ void Global::readArguments(int nargs, char* args[]) {
       if (!strcmp(v, "BOTH")) strand = Strand::BOTH_STRANDS;
       else if (!strcmp(v, "PLUS")) strand = Strand::PLUS_STRAND;
       else {
-        std::cerr << "ERROR: Unknown strand (not in {BOTH, PLUS})" << std::endl;
+        printHelp();
+        log_line("ERROR", "Unknown expression following --strand");
         exit(4);
       }
     } else if (!strcmp(a, "--bg-model-order")) {
       bgModelOrder = std::stoi(need(i, nargs, args, printHelp));
       if (bgModelOrder < 0 || bgModelOrder > 2) {
-        std::cerr << "ERROR: background model orders above 2 are not supported" << std::endl;
+        log_line("ERROR", "background model orders above 2 are not supported");  // (not in the reference: its alpha vector has three entries, src/Global.cpp:49)
         exit(4);
       }
     } else if (!strcmp(a, "--no-neighbor-filtering")) {
@@ -168,13 +186,13 @@ void Global::readArguments(int nargs, char* args[]) {
     } else if (!strcmp(a, "--max-optimized-patterns")) {
       maximum_optimized_patterns = std::stoi(need(i, nargs, args, printHelp));
     } else if (!strcmp(a, "--version")) {
-      std::cout << "peng_motif version " << VERSION_NUMBER << std::endl;
+      std::cout << "peng_motif " << VERSION_NUMBER << std::endl;  // (src/Global.cpp:299-301: without the word)
       exit(0);
     } else if (!strcmp(a, "-h")) {
       printHelp();
       exit(0);
     } else {
-      if (pengk_host::rank() == 0) std::cerr << "WARNING: Ignoring unknown option " << a << std::endl;
+      if (pengk_host::rank() == 0) log_line("WARNING", std::string("Ignoring unknown option ") + a);
     }
   }
 }
