@@ -130,9 +130,16 @@ def sweep_roofline(W, sweep_ms):
     background probabilities, expected, log-p and z written -- over the HIP-event time of pengk_pattern_stats."""
     alg = 28 * 4 ** W
     ach = alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms and sweep_ms > 0 else 0.0
+    traffic, source = None, None
+    try:  # (the PMC passes of the committed profile, like K1's: the driver cannot run rocprofv3)
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_by_config.json"))).get("sweep_W%d" % W)
+        if t:
+            traffic, source = t["hbm_bytes_per_launch"], "profiles/traffic_by_config.json[sweep_W%d]: rocprofv3 --pmc passes at commit %s, not this run" % (W, t["commit"])
+    except Exception:
+        pass
     return {"kernel": "stats_kernel<%d> (K2+K3: background probabilities of orders 0..2, strand aggregation, expected, log-p, z)" % W,
             "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-            "traffic": None, "algorithmic_bytes_per_launch": alg, "ms": round(sweep_ms, 5),
+            "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_launch": alg, "ms": round(sweep_ms, 5),
             "note": "28 B per pattern (SURVEY.md 8d); at W = 10 the 29 MB stay in L2 / Infinity Cache and the launch is ~20 us: launch-bound, not byte-bound"}
 
 

@@ -288,6 +288,7 @@ def test_the_committed_traffic_profile_is_not_older_than_the_count_kernels():
     for key, entry in prof.items():
         stamp = entry.get("commit")
         assert stamp and git("cat-file", "-e", stamp + "^{commit}").returncode == 0, (key, stamp)
-        r = git("diff", "--quiet", stamp, "--", "peng-motif_amd/csrc/count.hip")  # (the working tree against the stamp)
-        assert r.returncode == 0, ("profiles/traffic_by_config.json[%s] was measured at %s and csrc/count.hip has changed since: "
-                                   "run tools/profile_round.sh again" % (key, stamp))
+        src = "peng-motif_amd/csrc/stats.hip" if key.startswith("sweep_") else "peng-motif_amd/csrc/count.hip"  # (K2+K3's entries: the sweep kernel)
+        r = git("diff", "--quiet", stamp, "--", src)  # (the working tree against the stamp)
+        assert r.returncode == 0, ("profiles/traffic_by_config.json[%s] was measured at %s and %s has changed since: "
+                                   "run tools/profile_round.sh again" % (key, stamp, src))

@@ -134,6 +134,16 @@ if k1 and complete and bench:
     path = os.path.join(prof, "traffic_by_config.json")
     allc = json.load(open(path)) if os.path.exists(path) else {}
     allc[key] = t
+    # K2+K3: the sweep kernel of the same profile (a thread reads 4 B of count per lane, uncalibrated width: raw FETCH_SIZE)
+    for name in agg:
+        if name.startswith("pengk::stats_kernel<"):
+            f, w = agg[name].get("FETCH_SIZE"), agg[name].get("WRITE_SIZE")
+            if f and w:
+                f, w = sum(f) / len(f) * KIB, sum(w) / len(w) * KIB
+                Ws = int(name.split("<")[1].split(">")[0])
+                allc["sweep_W%d" % Ws] = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of stats_kernel<%d> per launch (raw values)" % Ws, "commit": commit,
+                                          "profile": tag, "fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_per_launch": f + w,
+                                          "algorithmic_bytes_per_launch": 28 * 4 ** Ws}
     json.dump(allc, open(path, "w"), indent=1)
     print("traffic entry", key, "%.3f GB per launch" % (total / 1e9))
 print("\n".join(lines[:60]))
