@@ -73,7 +73,7 @@ int pengk_set_stream(pengk_ctx* ctx, void* hip_stream);
 /* Tunables / introspection.  Options: "count_impl" 0 = auto, 1 = direct global atomics, 2 = partitioned LDS
  * histograms (W = 8 .. 14); "n_windows_hint" = total windows of the attached items (sizes the key buffer
  * tightly; set it after pengk_set_sequences); "key_cap_override" (test hook) entries per bucket region of the
- * partitioned count, 0 = automatic; "iupac_group_bytes" (test hook) scratch budget for one group of large
+ * partitioned count, 0 = automatic; "sweep_pairs" 1 (default) / 0: both strands from W = 12 on, a pattern and its reverse complement evaluated once (0: one thread per pattern; same bits); "iupac_group_bytes" (test hook) scratch budget for one group of large
  * patterns in pengk_iupac_aggregate, 0 = 1 GiB; "em_fast" 2 (default) / 1 / 0, see pengk_em.  Info: "deferred_items" (of the last pengk_count;
  * synchronises), "num_cu"; of the last pengk_em / pengk_em_device call in the serial mode with its blocks evaluated ahead
  * (synchronise): "em_fetched_blocks" (blocks a chain added term by term), "em_mispredicted_blocks" (of those: blocks

@@ -138,6 +138,7 @@ int pengk_destroy(pengk_ctx* ctx) {
   if (ctx->d_em_blocks) (void)hipFree(ctx->d_em_blocks);
   if (ctx->d_em_counters) (void)hipFree(ctx->d_em_counters);
   if (ctx->d_em_look) (void)hipFree(ctx->d_em_look);
+  if (ctx->d_pair_mids) (void)hipFree(ctx->d_pair_mids);
   for (int l = 0; l < 3; ++l) {
     if (ctx->em_streams[l]) (void)hipStreamDestroy(ctx->em_streams[l]);
     if (ctx->em_join[l]) (void)hipEventDestroy(ctx->em_join[l]);
@@ -196,6 +197,10 @@ int pengk_set_option(pengk_ctx* ctx, const char* name, int64_t value) {
   if (strcmp(name, "em_head_blocks") == 0) {
     if (value < 1 || value > 64) return PENGK_ERR_ARG;
     ctx->em_head_blocks = (int)value;
+    return PENGK_OK;
+  }
+  if (strcmp(name, "sweep_pairs") == 0) {
+    ctx->sweep_pairs = value != 0;
     return PENGK_OK;
   }
   if (strcmp(name, "em_lean_div") == 0) {

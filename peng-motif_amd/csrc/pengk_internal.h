@@ -28,6 +28,9 @@ struct pengk_ctx {
   size_t em_tables_bytes = 0;
   void* d_em_blocks = nullptr;   // K5 serial mode, blocks ahead of their chain: block sums | block records (em.hip)
   size_t em_blocks_bytes = 0;
+  void* d_pair_mids = nullptr;   // K2+K3 twin tiles: the middles m <= rc(m), one workgroup each (stats.hip)
+  size_t pair_mids_bytes = 0;
+  int pair_mids_W = 0;           // the pattern length that list was made for
   void* d_em_look = nullptr;     // K5 serial mode, two launches per iteration: the look-back words of the spans (em.hip)
   size_t em_look_bytes = 0;
   uint32_t em_epoch = 0;         // ... and the epoch of the last launch that wrote them
@@ -56,6 +59,7 @@ struct pengk_ctx {
                                 // (W >= 10; else as 1), 1 = the scan, block after block, 0 = dependent additions
   int em_head_blocks = 1;       // K5 serial mode, W >= 10: the first blocks of every cell folded from zero beside the evaluation of the others
                                 // (1 = block 0 only: more measured level at 16 PWMs, slower at 2 and at 1000, profiles/r05_em_kernels.log)
+  int sweep_pairs = 1;          // K2+K3, both strands, W >= 12: a pattern and its reverse complement evaluated once (stats_pair_kernel)
   int em_lean_div = 1;          // K5 serial mode: the weights' divisions without range scaling where a PWM's operand ranges allow (em.hip, lean_div)
   int em_fast = 2;              // K5: 2 = the reference's serial float32 sums, bit-exact (default); 1 = one reciprocal per k-mer weight, 0 = the reference's three divisions
   int count_impl = 0;           // 0 auto, 1 direct atomics, 2 partitioned LDS histograms

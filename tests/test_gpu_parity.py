@@ -404,6 +404,36 @@ def _synth_cases():
     return json.load(open(path))
 
 
+@pytest.mark.parametrize("mirrored", [True, False])
+@pytest.mark.parametrize("W", [12, 14])
+def test_sweep_twin_tiles_equal_the_per_pattern_kernel(ctx, W, mirrored):
+    """Both strands, W >= 12: stats_pair_kernel evaluates a pattern and its reverse complement once (a tile of 64 x 64
+    patterns and the tile of the twins, handed over through LDS; csrc/stats.hip) -- every table must carry the bits of the
+    one-thread-per-pattern kernel (option sweep_pairs = 0; that kernel is the one the goldens and the reference checksums
+    pin at W <= 10 and, through sha256, at W = 12): all background orders, expected, log-p, z, for k = 0 / 1 / 2, on a
+    mirrored count table and on an un-mirrored one (twins with different counts: log-p and z are then worked out for
+    both), palindromic patterns and the 64 tiles that are their own twins included (the whole table is compared)."""
+    ctx.synth(5, 0, 60000 if W == 12 else 200000, 200, W)
+    counts, ltot, bg = ctx.count_bg(True)
+    if mirrored:
+        ctx.mirror(W, counts)
+    V = ctx.bg_model(bg, 2)
+    try:
+        for k, max_k in ((2, 2), (0, 2), (1, 1)):
+            ctx.set_option("sweep_pairs", 0)
+            want = [a.to_host().copy() for a in ctx.pattern_stats(W, True, k, max_k, V, ltot, counts)]
+            ctx.set_option("sweep_pairs", 1)
+            got = [a.to_host() for a in ctx.pattern_stats(W, True, k, max_k, V, ltot, counts)]
+            for name, g, w in zip(("bgprob", "expected", "logp", "z"), got, want):
+                assert g.tobytes() == w.tobytes(), (W, mirrored, k, max_k, name, int((g.view(np.uint32) != w.view(np.uint32)).sum()))
+        c = counts.to_host()
+        if not mirrored:
+            rc = np.array([po.revcomp(x, W) for x in range(0, 4 ** W, 4 ** W // 4096 + 1)])
+            assert (c[::4 ** W // 4096 + 1] != c[rc]).any()  # (the table really is un-mirrored)
+    finally:
+        ctx.set_option("sweep_pairs", 1)
+
+
 @pytest.mark.parametrize("case", _synth_cases(), ids=lambda c: "W%d_%s_%d" % (c["W"], c["strand"], c["n_seq"]))
 def test_device_generated_input_against_reference_checksums(ctx, case):
     """Sequences generated ON THE DEVICE (pengk_synth_sequences) -> fused count -> bg model -> sweep, compared
