@@ -135,13 +135,13 @@ if k1 and complete and bench:
     allc = json.load(open(path)) if os.path.exists(path) else {}
     allc[key] = t
     # K2+K3: the sweep kernel of the same profile (a thread reads 4 B of count per lane, uncalibrated width: raw FETCH_SIZE)
-    for name in agg:
-        if name.startswith("pengk::stats_kernel<"):
+    for name in sorted(agg):  # (stats_pair_kernel -- both strands from W = 12 on, the kernel the step runs -- comes second and wins)
+        if name.startswith("pengk::stats_kernel<") or name.startswith("pengk::stats_pair_kernel<"):
             f, w = agg[name].get("FETCH_SIZE"), agg[name].get("WRITE_SIZE")
             if f and w:
                 f, w = sum(f) / len(f) * KIB, sum(w) / len(w) * KIB
                 Ws = int(name.split("<")[1].split(">")[0])
-                allc["sweep_W%d" % Ws] = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of stats_kernel<%d> per launch (raw values)" % Ws, "commit": commit,
+                allc["sweep_W%d" % Ws] = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of %s per launch (raw values)" % name.replace("pengk::", ""), "commit": commit,
                                           "profile": tag, "fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_per_launch": f + w,
                                           "algorithmic_bytes_per_launch": 28 * 4 ** Ws}
     json.dump(allc, open(path, "w"), indent=1)
