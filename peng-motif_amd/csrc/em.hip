@@ -570,10 +570,11 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
     // so it is folded here, beside the evaluation of all the other blocks, instead of at the head of every chain
     // (the chains: 37 -> 30 us per iteration for 16 PWMs).  Four waves per workgroup (a block staged per wave in a
     // quarter of the span buffer), a cell each; the record says SUM_BEHIND and carries the sum.
-    const uint32_t xi = lin, xslot = xi >> 3;
     constexpr uint32_t XW = (G::CELLS + 3u) / 4u;  // workgroups per PWM
-    const uint32_t pw = (xi & 7u) + 8u * (xslot / XW), cell = 4u * (xslot % XW) + wave;
-    if (pw >= n_pwm || wave >= 4u || cell >= G::CELLS || run_now[pw] == 0u || bad[pw]) return;
+    uint32_t pw, xunit;
+    if (!group_map(lin, n_pwm, XW, pw, xunit)) return;
+    const uint32_t cell = 4u * xunit + wave;
+    if (wave >= 4u || cell >= G::CELLS || run_now[pw] == 0u || bad[pw]) return;
     seqsum::lds_float* buf = (seqsum::lds_float*)span + wave * seqsum::BLOCK;
     const float* w = wbuf + (size_t)pw * G::NP;
     // ... and the `head_blocks` - 1 blocks behind it, one after the other from the exact sum: the sum doubles from block
@@ -621,9 +622,8 @@ __global__ __launch_bounds__(64 * SPAN_EVAL_WAVES) void em_span_eval_kernel(cons
     PENGK_WG_TRACE_END(1, lin);
     return;
   }
-  const uint32_t sl = lin - extra_wgs, slot = sl >> 3;
-  const uint32_t pw = (sl & 7u) + 8u * (slot / G::SPANS), sp = slot % G::SPANS;
-  if (pw >= n_pwm) return;
+  uint32_t pw, sp;
+  if (!group_map(lin - extra_wgs, n_pwm, G::SPANS, pw, sp)) return;
   // The span's 64 KiB are asked for FIRST, together with the PWM's flags; the estimates below (another round trip: the
   // cells' block sums) are worked out while the span is on its way.
   constexpr uint32_t T = 64u * SPAN_EVAL_WAVES, PER = 4096u / T;
@@ -737,9 +737,9 @@ __global__ __launch_bounds__(64) void em_chain_store_kernel(const uint32_t* __re
                                                             unsigned long long* __restrict__ counters) {
   using G = BlockGeo<W>;
   PENGK_WG_TRACE_BEGIN(3);
-  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
-  const uint32_t cell = slot % G::CELLS, pw = (lin & 7u) + 8u * (slot / G::CELLS);
-  if (pw >= n_pwm) return;
+  const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
+  uint32_t pw, cell;
+  if (!group_map(lin, n_pwm, G::CELLS, pw, cell)) return;
   __shared__ __attribute__((aligned(16))) float lds[seqsum::WALK_LDS_FLOATS];
   seqsum::WalkCounts wc;
   const uint32_t lane = threadIdx.x;
@@ -1029,11 +1029,11 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
             if (!B::PREDICT_IN_EVAL)
               hipLaunchKernelGGL((em_block_predict_kernel<W>), dim3(B::CELLS, (unsigned)nb), dim3(64), 0, st, run_now, bad_now,
                                  (const float*)sums, rec, (uint32_t)ctx->em_test_skew);
-            const uint64_t xwgs = (uint64_t)groups * ((B::CELLS + 3) / 4), swgs = xwgs + (uint64_t)groups * B::SPANS;
+            const uint64_t xwgs = (uint64_t)nb * ((B::CELLS + 3) / 4), swgs = xwgs + (uint64_t)nb * B::SPANS;  // (group_map: exactly the PWMs' workgroups)
             hipLaunchKernelGGL((em_span_eval_kernel<W>), dim3(1024u, (unsigned)((swgs + 1023u) / 1024u)), dim3(64 * SPAN_EVAL_WAVES), 0, st,
                                run_now, (const float*)tables, rec, bad_now, (uint32_t)nb, (const float*)sums,
                                (uint32_t)ctx->em_test_skew, (uint32_t)xwgs, (uint32_t)std::min<uint64_t>(ctx->em_head_blocks, B::NBLK));
-            hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
+            hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), (unsigned)nb), dim3(64), 0, st, run_now, bad_now,
                                (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters);
             continue;
           }
@@ -1046,7 +1046,7 @@ int launch_serial_ahead(pengk_ctx* ctx, int64_t n_pwm, float* d_pwms, float satu
                                                    (uint32_t)ctx->em_test_lookback);  // (em_fused.hip)
             if (rc_fused) return rc_fused;
           }
-          hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), groups), dim3(64), 0, st, run_now, bad_now,
+          hipLaunchKernelGGL((em_chain_store_kernel<W>), dim3((unsigned)(4 * W), (unsigned)nb), dim3(64), 0, st, run_now, bad_now,
                              (const float*)tables, (const seqsum::BlockRecord*)rec, cellsum, (uint32_t)nb, ctx->d_em_counters);
         }
       }

@@ -63,6 +63,25 @@ struct BlockGeo {
   static __device__ __forceinline__ uint32_t high_digit(uint32_t p, uint32_t sp) { return (sp >> (2u * (p - 7u))) & 3u; }
 };
 
+// Which (PWM, unit) a workgroup takes -- unit = a span, a chain, a group of block-0 cells; U of them per PWM.  PWMs in whole
+// groups of eight keep one XCD each (workgroup i runs on XCD i mod 8: a PWM's spans, and behind them its chains, stay with
+// one L2; 1000 PWMs: 35.5 against 37.5 ms).  The PWMs of a last, partial group are dealt unit by unit over ALL XCDs
+// instead: pinned to one XCD each, a batch of 2 PWMs ran its evaluation on a quarter of the chip (W = 12, 2 PWMs -- what a
+// rank of the 8-GPU configs[3] run holds: evaluation kernel 205 us beside a 68 us weights kernel).
+__device__ __forceinline__ bool group_map(uint32_t idx, uint32_t n_pwm, uint32_t U, uint32_t& pw, uint32_t& unit) {
+  const uint32_t full = n_pwm >> 3, rem = n_pwm & 7u, full_wgs = full * 8u * U;
+  if (idx < full_wgs) {
+    pw = (idx & 7u) + 8u * ((idx >> 3) / U);
+    unit = (idx >> 3) % U;
+    return true;
+  }
+  const uint32_t j = idx - full_wgs;
+  if (j >= rem * U) return false;
+  pw = 8u * full + j % rem;
+  unit = j / rem;
+  return true;
+}
+
 // The binade of a block from the estimates of the sum in front of it and behind it, or NO_BINADE when the two -- widened
 // by 2^-9, far more than a float32 chain of 4^13 terms drifts from the exact sum in practice -- do not share one.  A wrong
 // guess costs time, never the result (seqsum.h).
