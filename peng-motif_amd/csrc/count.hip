@@ -828,8 +828,12 @@ __global__ __launch_bounds__(1024) void count_hist_kernel(const uint16_t* __rest
   const uint32_t per = (n_slices + bpb - 1) / bpb;
   const uint32_t first = slice0 + j * per, last = slice0 + min(n_slices, j * per + per);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  // (the next slice's fill is asked for while this one's keys are counted: on a small shard -- a rank's eighth of the bench
+  // input: ~240 groups per slice -- a slice is two dependent round trips, fill then keys, and the kernel their sum)
+  uint32_t fill_next = first + wave < last ? slice_fill[(size_t)(first + wave) * nb + b] : 0u;
   for (uint32_t s = first + wave; s < last; s += 16) {
-    const uint32_t n8 = slice_fill[(size_t)s * nb + b] >> 3;  // groups of 8 keys (16 B); fill is a multiple of 64
+    const uint32_t n8 = fill_next >> 3;  // groups of 8 keys (16 B); fill is a multiple of 64
+    if (s + 16 < last) fill_next = slice_fill[(size_t)(s + 16) * nb + b];
     const uint4* src = reinterpret_cast<const uint4*>(keys + ((size_t)s * nb + b) * slice_cap);
     auto count8 = [&](const uint4& v) {
       const uint32_t k[8] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16, v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
@@ -849,7 +853,18 @@ __global__ __launch_bounds__(1024) void count_hist_kernel(const uint16_t* __rest
 #pragma unroll
       for (int q = 0; q < 8; ++q) count8(v[q]);
     }
-    for (; i < n8; i += 64) count8(src[i]);
+    if (i < n8) {  // the rest (a whole small slice): up to seven loads, all in flight together (one after the other they were its time)
+      uint4 v[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // (keys that count8 skips)
+        const u32x4 t = i + 64u * q < n8 ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&src[i + 64 * q])) : ones;
+        v[q] = make_uint4(t.x, t.y, t.z, t.w);
+      }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) count8(v[q]);
+    }
   }
   __syncthreads();
   uint32_t* dst = temp + ((size_t)f << PAYLOAD_BITS);
