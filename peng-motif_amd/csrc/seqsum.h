@@ -373,10 +373,14 @@ __device__ __forceinline__ float walk_chain(const Source& src, const BlockRecord
   uint32_t ha = NO_BINADE, hb = NO_BINADE;  // the blocks in bufa / bufb (or on their way)
   bool a_first = true;                      // which of the two comes first in the chain
   bool restaged = false;                    // that one was asked for again after the other: the counted wait does not cover it
+  uint4 r_next = first_records;  // (this lane's record of the first chunk, loaded by the caller together with what else it needs)
 #pragma unroll 1
   for (uint32_t base = 0; base < n_blocks; base += 64u) {
-    // (first_records = this lane's record of the first chunk, loaded by the caller together with what else it needs)
-    const uint4 r = base == 0u ? first_records : reinterpret_cast<const uint4*>(rec)[base + lane];
+    // The next chunk's records are asked for while this one is walked (W = 12: sixteen chunks per chain, each a dependent
+    // round trip in front of its walk).  The load is older than every block this chunk stages, so the counted waits
+    // below still cover what they name.
+    const uint4 r = r_next;
+    if (base + 64u < n_blocks) r_next = reinterpret_cast<const uint4*>(rec)[base + 64u + lane];
     unsigned long long open = __builtin_amdgcn_ballot_w64(r.x == NO_BINADE);
     auto open_after = [&](uint32_t b) {  // the next block of this chunk without a binade behind block b, or NO_BINADE
       const uint32_t j = b - base;
