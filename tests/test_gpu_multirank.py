@@ -116,17 +116,28 @@ def test_two_ranks_on_a_synthetic_set_and_their_memory(tmp_path):
     assert strip_timing(res[0][2]) == strip_timing(se) and res[1][1] == b""
     # memory: with the staged path (PENGK_NO_STREAMING=1), which holds a shard's byte codes to the end -- the streaming
     # path gives every chunk's codes back as soon as they are packed, and its peak says little about the shard
+    # Every figure is the SMALLER peak of three runs: a process's peak carries transients that have nothing to do with its
+    # shard (allocator arenas of the reader's threads, the HIP runtime's staging buffers: +100 MB one run in three on a
+    # busy box), and they only ever add.
     keep = {"PENGK_NO_STREAMING": "1"}
-    whole = run_plain([fa, "-w", "10"], tmp_path, tag="plainkeep", timing=True, extra_env=keep)
-    ranks = run_ranks([fa, "-w", "10"], 2, tmp_path, tag="rankskeep", timing=True, extra_env=keep)
-    assert (ranks[0][1], ranks[0][3], ranks[0][4]) == (so, meme, js)
-    base = run_ranks([small, "-w", "10"], 2, tmp_path, tag="small", timing=True, extra_env=keep)
-    whole_small = run_plain([small, "-w", "10"], tmp_path, tag="plainsmall", timing=True, extra_env=keep)
-    grow_plain = peak_rss_mb(whole[2]) - peak_rss_mb(whole_small[2])
+    REPEATS = 3
+    peaks = {"whole": [], "whole_small": [], "ranks": [[], []], "base": [[], []]}
+    for rep in range(REPEATS):
+        whole = run_plain([fa, "-w", "10"], tmp_path, tag="plainkeep%d" % rep, timing=True, extra_env=keep)
+        ranks = run_ranks([fa, "-w", "10"], 2, tmp_path, tag="rankskeep%d" % rep, timing=True, extra_env=keep)
+        assert (ranks[0][1], ranks[0][3], ranks[0][4]) == (so, meme, js)
+        base = run_ranks([small, "-w", "10"], 2, tmp_path, tag="small%d" % rep, timing=True, extra_env=keep)
+        whole_small = run_plain([small, "-w", "10"], tmp_path, tag="plainsmall%d" % rep, timing=True, extra_env=keep)
+        peaks["whole"].append(peak_rss_mb(whole[2]))
+        peaks["whole_small"].append(peak_rss_mb(whole_small[2]))
+        for rank in range(2):
+            peaks["ranks"][rank].append(peak_rss_mb(ranks[rank][2]))
+            peaks["base"][rank].append(peak_rss_mb(base[rank][2]))
+    grow_plain = min(peaks["whole"]) - min(peaks["whole_small"])
     for rank in range(2):
-        grow = peak_rss_mb(ranks[rank][2]) - peak_rss_mb(base[rank][2])
+        grow = min(peaks["ranks"][rank]) - min(peaks["base"][rank])
         # one process: file text + codes + packed stream for 270k more records; a rank: for 135k more
-        assert grow < 0.65 * grow_plain, (rank, grow, grow_plain)
+        assert grow < 0.65 * grow_plain, (rank, grow, grow_plain, peaks)
 
 
 def test_a_fasta_error_in_one_shard_ends_every_rank(tmp_path):
