@@ -20,6 +20,10 @@ done
 for c in 1 5 37; do
   PENGK_READ_CHUNKS=$c PENGK_READ_THREADS=3 ASAN_OPTIONS=detect_leaks=0 $T/ingest tests/golden/MafK.fasta > /dev/null && echo "ingest ok MafK.fasta in $c chunks"
 done
+# round 5: paths that are not regular files -- a pipe / /dev/stdin is spooled into a memory file, a directory is an empty set
+cat tests/golden/MafK.fasta | ASAN_OPTIONS=detect_leaks=0 $T/ingest /dev/stdin > $T/pipe.out && ASAN_OPTIONS=detect_leaks=0 $T/ingest tests/golden/MafK.fasta > $T/file.out \
+  && cmp -s $T/pipe.out $T/file.out && echo "ingest ok MafK.fasta through a pipe"
+mkdir -p $T/dir.fa && ASAN_OPTIONS=detect_leaks=0 $T/ingest $T/dir.fa > /dev/null && echo "ingest ok a directory (empty set)"
 mkdir $T/g
 for r in 0 1 2; do ASAN_OPTIONS=detect_leaks=0 $T/ingest tests/golden/torture.fa $r 3 $T/g > $T/g/out$r 2> $T/g/err$r & done
 wait
